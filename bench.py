@@ -1,0 +1,254 @@
+"""Benchmark of the north-star path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One "step" = one MNIST-MLP training step (784->512->10, bias, batch 1024 PER GPU, loss.mse,
+AdaBelief lr 1e-3): forward, backward, gradient all-reduce over RCCL (N > 1), optimizer update.
+Inputs are synthetic and resident in HBM before the timed region.  `value` is the whole-job
+aggregate steps/s (N ranks x K steps / max-over-ranks wall time): weak scaling.
+
+The same JSON line also carries BASELINE's second headline, the 4096^2 fp32 matmul
+forward+backward (`secondary`, replicas on every rank), the roofline of the dominant kernel
+(the MFMA SGEMM; measured with HIP events on the library's stream) and the CPU baseline
+(the numpy oracle timed on this host's cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (dense fp32 matrix)
+HBM_PEAK_GBS = 8000.0               # HBM3E spec
+MATMUL_N = 4096
+MATMUL_FLOP = 3 * 2 * MATMUL_N ** 3  # fwd + dA + dB
+MLP_GEMM_FLOP = 3 * 2 * 1024 * (784 * 512 + 512 * 10)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--matmul-iters", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    else:
+        world, rank = 1, 0
+
+    import numpy as np
+    import lightgrad_amd as light
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipDevice, lib as L
+    from lightgrad_amd.dist import RcclCommunicator, SingleProcess, DataParallel
+
+    lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
+    info = HipDevice.info()
+    comm = RcclCommunicator(rank, world) if world > 1 else SingleProcess()
+
+    def wall_max(seconds):
+        """max over ranks (the slowest rank defines the job's time)"""
+        if world == 1:
+            return seconds
+        t = HipTensor.from_numpy(np.asarray([seconds], np.float32), requires_grad=False)
+        comm.allreduce_max_(t)
+        return float(t.numpy()[0])
+
+    def fence():
+        comm.barrier()
+        HipDevice.synchronize()
+
+    # ------------------------------------------------------------------ MLP training step
+    class MLP(light.nn.Module):
+        def __init__(self):
+            light.nn.Module.__init__(self)
+            self.l1 = light.nn.Linear(784, 512)
+            self.l2 = light.nn.Linear(512, 10)
+
+        def forward(self, x):
+            return self.l2(self.l1(x.reshape(-1, 784)).relu())
+
+    np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
+    model = MLP().map_parameters(lambda p: p.hip())
+    dp = DataParallel(model.parameters(), comm)
+    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale)
+    rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
+    x = HipTensor.from_numpy(rng.uniform(0, 1, (1024, 784)).astype(np.float32))
+    labels = rng.randint(0, 10, 1024)
+    onehot_np = np.zeros((1024, 10), np.float32)
+    onehot_np[np.arange(1024), labels] = 1
+    onehot = HipTensor.from_numpy(onehot_np)
+
+    def step():
+        loss = light.loss.mse(model(x), onehot)
+        opt.zero_grad()
+        loss.backward()
+        dp.sync_gradients()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = wall_max(time.perf_counter() - t0)
+    final_loss = loss.item()
+    assert np.isfinite(final_loss), final_loss
+    steps_per_s = world * args.steps / elapsed
+    digest = dp.parameter_digest()
+    if world > 1:                                    # replicas must still be identical
+        d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
+        comm.allreduce_max_(d)
+        dmax, dmin = d.numpy()
+        assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
+
+    # ------------------------------------------------------------------ 4096^2 matmul forward + backward
+    np.random.seed(0)
+    a = HipTensor.from_numpy(np.random.uniform(-1, 1, (MATMUL_N, MATMUL_N)).astype(np.float32))
+    b = HipTensor.from_numpy(np.random.uniform(-1, 1, (MATMUL_N, MATMUL_N)).astype(np.float32))
+
+    def matmul_iter():
+        a.zero_grad()
+        b.zero_grad()
+        y = a @ b
+        y.backward(allow_fill=True)
+
+    for _ in range(3):
+        matmul_iter()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.matmul_iters):
+        matmul_iter()
+    fence()
+    mm_elapsed = wall_max(time.perf_counter() - t0)
+    mm_tflops = world * args.matmul_iters * MATMUL_FLOP / mm_elapsed / 1e12
+
+    # ------------------------------------------------------------------ roofline of the dominant kernel (HIP events)
+    import ctypes
+
+    def event():
+        e = ctypes.c_void_p()
+        L.check(lib.lg_event_create(ctypes.byref(e)))
+        return e
+
+    def time_launches(fn, n):
+        fn()
+        e0, e1 = event(), event()
+        L.check(lib.lg_event_record(e0))
+        for _ in range(n):
+            fn()
+        L.check(lib.lg_event_record(e1))
+        ms = ctypes.c_float()
+        L.check(lib.lg_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        lib.lg_event_destroy(e0)
+        lib.lg_event_destroy(e1)
+        return ms.value / n
+
+    c = HipTensor.empty((MATMUL_N, MATMUL_N), requires_grad=False)
+    n = MATMUL_N
+    gemm_ms = {}
+    for tag, (ta, tb) in {"NN": (0, 0), "NT": (0, 1), "TN": (1, 0)}.items():
+        gemm_ms[tag] = time_launches(lambda: L.check(lib.lg_gemm_f32(ta, tb, n, n, n, a.ptr, n, 0, b.ptr, n, 0, c.ptr, n, 0, 1, 0)), 10)
+    gemm_tf = {k: 2 * n ** 3 / (v * 1e-3) / 1e12 for k, v in gemm_ms.items()}
+    roofline = {"kernel": "sgemm_mfma<128,128,32> NN 4096^3", "bound": "mfma", "achieved": round(gemm_tf["NN"], 2),
+                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf["NN"] / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(gemm_ms["NN"], 4),
+                "algorithmic_flop_per_launch": 2 * n ** 3}
+    # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache)
+    big = (16384, 8192)
+    nbig = big[0] * big[1]
+    p, q, r = (HipTensor.empty(big, requires_grad=False) for _ in range(3))
+    p.fill(0.5)
+    q.fill(0.25)
+    st = L.i64(p.strides)
+    sh = L.i64(big)
+    hbm = {}
+
+    def ew(op, out, ins):
+        args_ = []
+        for t in ins + [None] * (4 - len(ins)):
+            args_ += [t.ptr if t is not None else None, st if t is not None else None]
+        return lambda: L.check(lib.lg_ew(op, 2, sh, out.ptr, st, None, None, *args_, 0.0))
+    for name, fn, bytes_per_elem in [("add", ew(L.EW_ADD, r, [p, q]), 12), ("mul", ew(L.EW_MUL, r, [p, q]), 12),
+                                     ("relu", ew(L.EW_RELU, r, [p]), 8), ("exp", ew(L.EW_EXP, r, [p]), 8),
+                                     ("relu_bwd", ew(L.EW_RELU_BWD, r, [p, q]), 12), ("iadd", ew(L.EW_ADD, p, [p, q]), 12)]:
+        ms = time_launches(fn, 5)
+        hbm[name] = {"ms": round(ms, 4), "GB/s": round(nbig * bytes_per_elem / (ms * 1e-3) / 1e9, 1)}
+    s_out = HipTensor.empty((), requires_grad=False)
+    for name, op in [("sum", L.RED_SUM), ("max", L.RED_MAX)]:
+        ms = time_launches(lambda: L.check(lib.lg_reduce(op, 2, sh, p.ptr, st, 3, s_out.ptr)), 5)
+        hbm[name] = {"ms": round(ms, 4), "GB/s": round(nbig * 4 / (ms * 1e-3) / 1e9, 1)}
+    col_out = HipTensor.empty((big[1],), requires_grad=False)
+    ms = time_launches(lambda: L.check(lib.lg_reduce(L.RED_SUM, 2, sh, p.ptr, st, 1, col_out.ptr)), 5)
+    hbm["sum_axis0"] = {"ms": round(ms, 4), "GB/s": round(nbig * 4 / (ms * 1e-3) / 1e9, 1)}
+    for v in hbm.values():
+        v["frac_of_8TBs"] = round(v["GB/s"] / HBM_PEAK_GBS, 3)
+    del p, q, r
+
+    # ------------------------------------------------------------------ CPU baseline (oracle, host cores)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import np_oracle as O                       # the checker, timed here ONLY as the reported CPU baseline
+        w0, xc, tc, _ = O.synthetic_mlp_problem(0)
+        o_opt = O.make_optimizer("adabelief")
+        w = {k: v.copy() for k, v in w0.items()}
+        t0 = time.perf_counter()
+        n_cpu = 0
+        while time.perf_counter() - t0 < 10.0 and n_cpu < 2000:
+            _, grads, _ = O.mlp_loss_and_grads(w, xc, tc)
+            for name in O.PARAM_ORDER:
+                w[name] += o_opt.delta(name, grads[name])
+            n_cpu += 1
+        cpu_steps = n_cpu / (time.perf_counter() - t0)
+        an, bn = a.numpy(), b.numpy()
+        t0 = time.perf_counter()
+        O.matmul_fwd_bwd(an, bn)
+        cpu_mm = time.perf_counter() - t0
+        cpu_baseline = {"value": round(cpu_steps, 2), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                        "sample": "%d MLP training steps (same shapes, numpy oracle, BLAS default threads) in ~10 s; "
+                                  "matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s" % (n_cpu, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
+                        "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3), "numpy": np.__version__}
+
+    if world > 1:
+        comm.close()
+    if rank == 0:
+        out = {
+            "metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
+                       "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
+                       "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused", "dispatch": "eager python tape",
+                       "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
+            "final_loss": round(final_loss, 6),
+            "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),
+            "secondary": {"metric": "matmul4096_fwd_bwd_tflops", "value": round(mm_tflops, 2), "unit": "TFLOP/s",
+                          "ms_per_iter": round(1e3 * mm_elapsed / args.matmul_iters, 4), "iters": args.matmul_iters,
+                          "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
+                          "scaling": "replicas", "gemm_kernel_tflops": {k: round(v, 2) for k, v in gemm_tf.items()}},
+            "roofline": roofline,
+            "roofline_hbm": hbm,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+/* lghip.h - C ABI of liblghip.so, the MI355X (gfx950) device library behind
+ * lightgrad's HipTensor backend.
+ *
+ * This is the drop-in boundary: plain C, opaque device
+ * pointers, caller-owned int64 shape/stride arrays that only need to live for
+ * the duration of a call.  Every entry point is what a lightgrad backend binds
+ * instead of the pyopencl calls of the reference's OpenCL backend; the
+ * reference interface each one replaces is cited as file:line (relative to the
+ * lightgrad repository).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative LG_E* code otherwise;
+ *     lg_last_error() returns a thread-local message for the last failure.
+ *     Nothing throws across the boundary.
+ *   - one process drives one GPU through one HIP stream owned by the library
+ *     (the reference: one in-order queue per device, opencl/device.py:79-84).
+ *     All device work is stream-ordered and asynchronous; only lg_memcpy_d2h,
+ *     lg_sync and lg_event_elapsed_ms block the host.  (The reference blocks
+ *     after every kernel: opencl/kernels.py:194, :334, :499.)
+ *   - shapes and strides are in ELEMENTS (not bytes), row-major order, at
+ *     most LG_MAX_DIMS dimensions; a stride of 0 broadcasts that dimension.
+ *   - arithmetic entry points are fp32 only; layout entry points (copy, fill)
+ *     take an item size in bytes and are bit-exact for any dtype.
+ */
+#ifndef LGHIP_H
+#define LGHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_MAX_DIMS 8
+
+/* error codes */
+#define LG_OK            0
+#define LG_EINVAL       -1   /* bad argument (shape/stride/op id/alignment) */
+#define LG_EHIP         -2   /* a HIP runtime call failed (message has hipGetErrorString) */
+#define LG_ENOMEM       -3   /* device allocation failed even after trimming the pool */
+#define LG_ENOTINIT     -4   /* lg_init has not been called */
+#define LG_ECOMM        -5   /* RCCL failure (liblghip_comm.so) */
+
+const char* lg_last_error(void);
+
+/* ---- runtime: device, stream, pool ---------------------------------------
+ * replaces OpenCLDevice (opencl/device.py:68-115): context + in-order queue +
+ * cl.tools.MemoryPool(ImmediateAllocator) (:83-84). */
+int lg_device_count(int* count);
+int lg_init(int device);                       /* idempotent for the same device */
+int lg_device(int* device);                    /* device bound by lg_init */
+typedef struct {
+    char     name[128];
+    char     arch[32];                          /* "gfx950" */
+    int32_t  compute_units;
+    int32_t  clock_mhz;                         /* max engine clock */
+    int32_t  wavefront_size;
+    int32_t  lds_bytes_per_cu;
+    uint64_t hbm_bytes;
+    int32_t  l2_bytes;
+    int32_t  reserved;
+} lg_device_info_t;
+int lg_device_info(lg_device_info_t* out);
+void* lg_stream(void);                          /* hipStream_t of the library (for liblghip_comm / profilers) */
+int lg_sync(void);                              /* block until the stream is idle */
+
+/* caching, stream-ordered allocator (replaces device.mem_pool.allocate, opencl/tensor.py:64).
+ * lg_free returns the block to the pool immediately: safe because all users are on one stream. */
+int lg_malloc(void** ptr, size_t bytes);
+int lg_free(void* ptr);
+int lg_pool_trim(void);                         /* hipFree every cached free block */
+int lg_pool_stats(uint64_t* reserved_bytes, uint64_t* in_use_bytes, uint64_t* hip_malloc_calls);
+
+/* transfers (replace cl.enqueue_copy: H2D opencl/tensor.py:78, D2H :84, D2D :92) */
+int lg_memcpy_h2d(void* dst, const void* src, size_t bytes);   /* returns after src may be reused */
+int lg_memcpy_d2h(void* dst, const void* src, size_t bytes);   /* synchronises the stream */
+int lg_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* stream-ordered */
+
+/* HIP events on the library's stream (timing in bench.py) */
+int lg_event_create(void** ev);
+int lg_event_record(void* ev);
+int lg_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int lg_event_destroy(void* ev);
+
+/* hipGraph capture of the library's stream: a launch-bound step (the ~100
+ * dispatches of one MLP training step) is recorded once and replayed with one
+ * host call.  While capturing, pool blocks are pinned to the graph so replays
+ * see the same addresses. */
+int lg_graph_begin(void);
+int lg_graph_end(void** graph_exec);
+int lg_graph_launch(void* graph_exec);
+int lg_graph_destroy(void* graph_exec);
+
+/* ---- layout ops (bit-exact, any dtype) ----------------------------------- */
+
+/* dst[idx] = src[idx] over `shape`; either side may be strided/broadcast.
+ * replaces the `atom` kernel with op 'o = a' used by contiguous()/copy()/getitem/setitem
+ * (opencl/tensor.py:103-116, opencl/ops.py:322-340). itemsize in {1,2,4,8}. */
+int lg_copy_strided(int itemsize, int ndim, const int64_t* shape,
+                    void* dst, const int64_t* dst_strides,
+                    const void* src, const int64_t* src_strides);
+
+/* dst[idx] = value over a strided view; `value_bits` holds the item in its low bytes.
+ * replaces clEnqueueFillBuffer (opencl/ops.py:172-177). */
+int lg_fill_strided(int itemsize, int ndim, const int64_t* shape,
+                    void* dst, const int64_t* dst_strides, uint64_t value_bits);
+
+/* ---- elementwise fp32 ------------------------------------------------------
+ * One generic entry point replacing the run-time generated `atom` kernels
+ * (opencl/kernels.py:24-195) for every op string used in opencl/ops.py:40-400.
+ * Operands a, b, c, d are fp32 inputs with their own strides (0 = broadcast);
+ * a NULL operand pointer means "this operand is the scalar `scalar`"
+ * (reference: scalar kernel arguments, kernels.py:139-150).
+ * out0/out1 are written; an output may alias an input with identical strides
+ * (in-place forms `a += b`, kernels.py `additional_read`).
+ * The library picks a vectorised contiguous path, an inner-dimension
+ * vectorised path or a generic strided path; results do not depend on it. */
+typedef enum {
+    /* unary: out0 = f(a) */
+    LG_EW_COPY = 0, LG_EW_NEG, LG_EW_EXP, LG_EW_LOG, LG_EW_RELU, LG_EW_SIGMOID,
+    LG_EW_TANH, LG_EW_SIN, LG_EW_COS, LG_EW_SQRT,
+    /* binary: out0 = f(a, b) */
+    LG_EW_ADD = 32, LG_EW_SUB, LG_EW_MUL, LG_EW_DIV, LG_EW_POW,
+    LG_EW_RELU_BWD,      /* a = saved input t, b = g :  g * (t >= 0)        (cpu/ops.py:229) */
+    LG_EW_SIGMOID_BWD,   /* a = y, b = g            :  y * (1 - y) * g      (cpu/ops.py:208) */
+    LG_EW_TANH_BWD,      /* a = y, b = g            :  (1 - y*y) * g        (cpu/ops.py:219) */
+    LG_EW_LOG_BWD,       /* a = x, b = g            :  (1 / x) * g          (cpu/ops.py:197) */
+    LG_EW_SIN_BWD,       /* a = t, b = g            :  cos(t) * g           (cpu/ops.py:166) */
+    LG_EW_COS_BWD,       /* a = t, b = g            :  -sin(t) * g          (cpu/ops.py:176) */
+    LG_EW_EQ,            /* (a == b) ? 1 : 0 */
+    LG_EW_GE,            /* (a >= b) ? 1 : 0 */
+    LG_EW_BIAS_RELU,     /* a = x, b = bias         :  max(x + b, 0)  (fused Linear bias + relu) */
+    /* ternary: out0 = f(a, b, c) */
+    LG_EW_MAX_BWD = 64,  /* a = x, b = extremum, c = g : g * (x == b)      (cpu/ops.py:272) */
+    LG_EW_FMA,           /* a * b + c (two roundings, like the tape's mul then add) */
+    /* two outputs: (out0, out1) = f(a, b, c[, d]) */
+    LG_EW_MUL_BWD = 96,  /* a, b, c = g : (g * b, a * g)                   (cpu/ops.py:84)  */
+    LG_EW_DIV_BWD,       /* a, b, c = g : (g / b, -a / b^2 * g)            (cpu/ops.py:94)  */
+    LG_EW_POW_BWD        /* a, b, c = g, d = y : (b * a^(b-1) * g, g * y * log a) (cpu/ops.py:105) */
+} lg_ew_op_t;
+
+int lg_ew(int op, int ndim, const int64_t* shape,
+          void* out0, const int64_t* out0_strides,
+          void* out1, const int64_t* out1_strides,
+          const void* a, const int64_t* a_strides,
+          const void* b, const int64_t* b_strides,
+          const void* c, const int64_t* c_strides,
+          const void* d, const int64_t* d_strides,
+          float scalar);
+
+/* ---- reductions fp32 -------------------------------------------------------
+ * replaces the multi-pass `reduce` kernel (opencl/kernels.py:344-501) as used by
+ * sum/max/min (opencl/ops.py:344-400).  Dimensions whose bit is set in
+ * `axis_mask` (bit i = dimension i) are reduced; `out` is CONTIGUOUS over the
+ * kept dimensions in their original order.  max/min are exact; sum is a
+ * tree reduction in fp32 (numpy uses pairwise blocks: agreement ~1e-6 rel). */
+typedef enum { LG_RED_SUM = 0, LG_RED_MAX = 1, LG_RED_MIN = 2 } lg_red_op_t;
+int lg_reduce(int op, int ndim, const int64_t* shape,
+              const void* in, const int64_t* in_strides,
+              uint32_t axis_mask, void* out);
+
+/* ---- SGEMM on MFMA ---------------------------------------------------------
+ * C[b] (M x N, row-major, leading dimension ldc) (+)= op(A[b]) @ op(B[b]), fp32
+ * in/out, fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ *   transA = 0: A[m*lda + k]      transA = 1: A[k*lda + m]
+ *   transB = 0: B[k*ldb + n]      transB = 1: B[n*ldb + k]
+ * so stride-permuted views (W.T(1,0) in nn.Linear, nn.py:96; the transposed
+ * operands of dot.backward, cpu/ops.py:116) are consumed WITHOUT the
+ * contiguous() copies and zero-padding copies of the reference
+ * (opencl/kernels.py:291-298, :319-320, :331).
+ * batch > 1: operand b starts at base + b*stride{A,B,C} elements (stride 0
+ * broadcasts an operand over the batch).  accumulate != 0 adds into C.
+ * replaces kernels.dot (opencl/kernels.py:201-337) called from opencl/ops.py:116-132. */
+int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                const float* A, int64_t lda, int64_t strideA,
+                const float* B, int64_t ldb, int64_t strideB,
+                float* C, int64_t ldc, int64_t strideC,
+                int64_t batch, int accumulate);
+
+/* ---- fused optimizer ---------------------------------
+ * One Adam/AdaBelief update of a contiguous parameter, numerically the
+ * expression sequence of optim.py:36-40 / :48-52 evaluated per element (one
+ * rounding per operation; the tape's `/` is multiply-by-reciprocal):
+ *   g' = g * gscale (skipped when gscale == 1)
+ *   m  = b1*m + (1-b1)*g';   s = belief ? g' - m : g';   v = b2*v + (1-b2)*s*s
+ *   p += ((-lr) * (m * inv_bias1)) * (1 / (sqrt(v * inv_bias2) + eps))
+ * with inv_bias1 = 1/(1 - b1^t), inv_bias2 = 1/(1 - b2^t) computed by the caller
+ * in double; every scalar is rounded once to fp32 inside (numpy's python-float rule).
+ * gscale folds the data-parallel 1/world_size into the update. */
+int lg_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                     double lr, double b1, double b2, double eps,
+                     double inv_bias1, double inv_bias2, double gscale, int belief);
+
+/* library build info: "liblghip <version> gfx950 <build date>" */
+const char* lg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGHIP_H */

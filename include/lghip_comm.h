@@ -1,0 +1,40 @@
+/* lghip_comm.h - C ABI of liblghip_comm.so: data-parallel collectives over
+ * RCCL/xGMI for the HipTensor backend.  Separate shared object so that the
+ * single-GPU path never loads RCCL.
+ *
+ * The reference has no distributed code at all; this is the
+ * MI355X-native addition for BASELINE config #4: one process per GPU, one
+ * fp32 sum all-reduce per training step over a single flat gradient bucket,
+ * enqueued on the compute stream of liblghip.so (lg_stream()) between
+ * backward() and optim.step() with no host synchronisation.
+ *
+ * Rendezvous: rank 0 calls lg_comm_get_unique_id and hands the 128 bytes to
+ * the other ranks out of band (the launcher's file/pipe); no network service.
+ * All functions return 0 or a negative LG_E* code (lghip.h); the message is
+ * available from lg_comm_last_error().
+ */
+#ifndef LGHIP_COMM_H
+#define LGHIP_COMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_COMM_ID_BYTES 128
+
+typedef enum { LG_COMM_SUM = 0, LG_COMM_MAX = 1 } lg_comm_op_t;
+
+const char* lg_comm_last_error(void);
+int lg_comm_get_unique_id(char id[LG_COMM_ID_BYTES]);
+int lg_comm_init(int rank, int nranks, const char id[LG_COMM_ID_BYTES]);   /* lg_init must have been called */
+int lg_comm_rank(int* rank, int* nranks);
+int lg_comm_allreduce_f32(float* buf, int64_t n, int op);                  /* in place, stream-ordered */
+int lg_comm_broadcast_f32(float* buf, int64_t n, int root);                /* in place, stream-ordered */
+int lg_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGHIP_COMM_H */

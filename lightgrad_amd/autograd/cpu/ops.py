@@ -1,0 +1,383 @@
+"""First-class ops of the numpy backend.
+
+Restates the arithmetic of the reference's `lightgrad/autograd/cpu/ops.py`
+(op by op; line numbers in each docstring) so that `CpuTensor` here produces
+the same numbers as the reference's CPU backend on the same inputs - it is
+pinned against fixtures generated from the reference (tests/golden/).
+
+Two gaps of the reference's CPU backend are closed here, following its OpenCL
+backend as SURVEY.md §8c prescribes:
+  * `sum.backward` (reference cpu/ops.py:293 is a TODO) = broadcast of the
+    gradient to the input shape                       (opencl/ops.py:353-368)
+  * `dot.backward` for batched operands swaps the last two axes instead of
+    reversing all axes                                (opencl/ops.py:127-132)
+`conv` (cpu/ops.py:298-356) is CNN-only and out of scope.
+"""
+import numpy as np
+from ..func import Function
+from .tensor import CpuTensor
+
+
+def _raw(x):
+    return x.data if isinstance(x, CpuTensor) else x
+
+
+def _numpy_op(fn_cls):
+    """Let an op be written on ndarrays: unwrap tensor arguments, wrap results
+    (reference helper `_use_tensor_data`, cpu/ops.py:8-21)."""
+
+    class Op(fn_cls):
+        def forward(ctx, *args, **kwargs):
+            out = fn_cls.forward(ctx, *[_raw(a) for a in args], **{k: _raw(v) for k, v in kwargs.items()})
+            return CpuTensor(data=out, dtype=out.dtype)
+
+        def backward(ctx, out_grad):
+            grads = fn_cls.backward(ctx, out_grad.data)
+            grads = grads if isinstance(grads, tuple) else (grads,)
+            return tuple(CpuTensor(data=g, dtype=g.dtype) for g in grads)
+
+    Op.__name__ = fn_cls.__name__
+    Op.__qualname__ = fn_cls.__qualname__
+    Op.__doc__ = fn_cls.__doc__
+    return Op
+
+
+def _op(*names, overwrite=False):
+    def deco(fn_cls):
+        op = _numpy_op(fn_cls)
+        for n in (names or (fn_cls.__name__,)):
+            CpuTensor.register_op(n, op, overwrite=overwrite)
+        return op
+    return deco
+
+
+""" Transformations """
+
+
+@_op("T", "transpose")
+class transpose(Function):
+    """ axis permutation view; backward = inverse permutation (cpu/ops.py:25-36) """
+    def forward(ctx, a, *axes):
+        ctx.save_for_backward(axes)
+        return np.transpose(a, axes=(axes if len(axes) > 0 else None))
+
+    def backward(ctx, out_grad):
+        axes, = ctx.get_saved_tensors()
+        if len(axes) == 0:
+            return out_grad.transpose()
+        inverse = [0] * len(axes)
+        for i, j in enumerate(axes):
+            inverse[j] = i
+        return out_grad.transpose(*inverse)
+
+
+@_op()
+class reshape(Function):
+    """ cpu/ops.py:38-47 """
+    def forward(ctx, a, *shape):
+        ctx.save_for_backward(a.shape)
+        return a.reshape(shape)
+
+    def backward(ctx, out_grad):
+        shape, = ctx.get_saved_tensors()
+        return out_grad.reshape(shape)
+
+
+""" Basic math """
+
+
+@_op()
+class neg(Function):
+    """ cpu/ops.py:52-58 """
+    def forward(ctx, a):
+        return -a
+
+    def backward(ctx, out_grad):
+        return -out_grad
+
+
+@_op()
+class add(Function):
+    """ cpu/ops.py:60-66 """
+    def forward(ctx, a, b):
+        return a + b
+
+    def backward(ctx, out_grad):
+        return out_grad, out_grad
+
+
+@_op(overwrite=True)
+class sub(Function):
+    """ first-class by name only; the `-` operator stays the composite (cpu/ops.py:68-74) """
+    def forward(ctx, a, b):
+        return a - b
+
+    def backward(ctx, out_grad):
+        return out_grad, -out_grad
+
+
+@_op()
+class mul(Function):
+    """ cpu/ops.py:76-84 """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a * b
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        return out_grad * b, a * out_grad
+
+
+@_op(overwrite=True)
+class div(Function):
+    """ cpu/ops.py:86-94 """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a / b
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        return out_grad / b, -a / b**2 * out_grad
+
+
+@_op()
+class pow(Function):
+    """ cpu/ops.py:96-105; the exponent gradient is always formed (NaN for a<0, as in the reference) """
+    def forward(ctx, a, b):
+        y = a ** b
+        ctx.save_for_backward(a, b, y)
+        return y
+
+    def backward(ctx, out_grad):
+        a, b, y = ctx.get_saved_tensors()
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return b * (a ** (b - 1)) * out_grad, out_grad * y * np.log(a)
+
+
+@_op("__matmul__", "dot")
+class dot(Function):
+    """ a @ b (cpu/ops.py:107-116); backward swaps the last two axes so that it is also
+    right for batched operands (opencl/ops.py:127-132) - identical to `.T` in 2-D """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return a @ b
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        return out_grad @ np.swapaxes(b, -1, -2), np.swapaxes(a, -1, -2) @ out_grad
+
+
+""" In-place operators: no backward, result aliases the input storage (cpu/ops.py:120-153) """
+
+
+@_op("__iadd__", overwrite=True)
+class iadd(Function):
+    def forward(ctx, t, other):
+        t += other
+        return t
+
+
+@_op("__isub__", overwrite=True)
+class isub(Function):
+    def forward(ctx, t, other):
+        t -= other
+        return t
+
+
+@_op("__imul__", overwrite=True)
+class imul(Function):
+    def forward(ctx, t, other):
+        t *= other
+        return t
+
+
+@_op("__itruediv__", overwrite=True)
+class itruediv(Function):
+    def forward(ctx, t, other):
+        t /= other
+        return t
+
+
+@_op()
+class fill(Function):
+    def forward(ctx, t, val):
+        t.fill(val)
+        return t
+
+
+""" Non-linearities """
+
+
+@_op()
+class sin(Function):
+    """ cpu/ops.py:158-166 """
+    def forward(ctx, t):
+        ctx.save_for_backward(t)
+        return np.sin(t)
+
+    def backward(ctx, out_grad):
+        t, = ctx.get_saved_tensors()
+        return np.cos(t) * out_grad
+
+
+@_op()
+class cos(Function):
+    """ cpu/ops.py:168-176 """
+    def forward(ctx, t):
+        ctx.save_for_backward(t)
+        return np.cos(t)
+
+    def backward(ctx, out_grad):
+        t, = ctx.get_saved_tensors()
+        return -np.sin(t) * out_grad
+
+
+@_op()
+class exp(Function):
+    """ saves the output (cpu/ops.py:178-187) """
+    def forward(ctx, t):
+        y = np.exp(t)
+        ctx.save_for_backward(y)
+        return y
+
+    def backward(ctx, out_grad):
+        y, = ctx.get_saved_tensors()
+        return y * out_grad
+
+
+@_op()
+class log(Function):
+    """ cpu/ops.py:189-197 """
+    def forward(ctx, t):
+        ctx.save_for_backward(t)
+        return np.log(t)
+
+    def backward(ctx, out_grad):
+        x, = ctx.get_saved_tensors()
+        return (1 / x) * out_grad
+
+
+@_op(overwrite=True)
+class sigmoid(Function):
+    """ cpu/ops.py:199-208 """
+    def forward(ctx, t):
+        y = 1 / (1 + np.exp(-t))
+        ctx.save_for_backward(y)
+        return y
+
+    def backward(ctx, out_grad):
+        y, = ctx.get_saved_tensors()
+        return y * (1 - y) * out_grad
+
+
+@_op(overwrite=True)
+class tanh(Function):
+    """ cpu/ops.py:210-219 """
+    def forward(ctx, t):
+        y = np.tanh(t)
+        ctx.save_for_backward(y)
+        return y
+
+    def backward(ctx, out_grad):
+        y, = ctx.get_saved_tensors()
+        return (1 - y**2) * out_grad
+
+
+@_op()
+class relu(Function):
+    """ gradient passes at exactly 0 (cpu/ops.py:221-229) """
+    def forward(ctx, t):
+        ctx.save_for_backward(t)
+        return np.maximum(t, 0.0)
+
+    def backward(ctx, out_grad):
+        t, = ctx.get_saved_tensors()
+        return out_grad * (t >= 0)
+
+
+""" Selectors """
+
+
+def _raw_index(idx):
+    if isinstance(idx, tuple):
+        return tuple(_raw(i) for i in idx)
+    return _raw(idx)
+
+
+@_op("__getitem__")
+class getitem(Function):
+    """ cpu/ops.py:234-246 """
+    def forward(ctx, a, idx):
+        idx = _raw_index(idx)
+        ctx.save_for_backward(a.shape, idx)
+        return a[idx]
+
+    def backward(ctx, out_grad):
+        shape, idx = ctx.get_saved_tensors()
+        grad = np.zeros(shape, dtype=np.float32)
+        grad[idx] = out_grad
+        return grad
+
+
+@_op("__setitem__")
+class setitem(Function):
+    """ cpu/ops.py:248-255 """
+    def forward(ctx, a, idx, val):
+        a[_raw_index(idx)] = val
+        return a
+
+
+""" Reductions """
+
+
+def _all_axes(x, axis):
+    return tuple(range(x.ndim)) if axis is None else axis
+
+
+@_op()
+class max(Function):
+    """ every tied maximum receives the full gradient (cpu/ops.py:260-272) """
+    def forward(ctx, x, axis=None, keepdims=False):
+        axis = _all_axes(x, axis)
+        val = np.max(x, axis=axis, keepdims=True)
+        ctx.save_for_backward(x, val, axis, keepdims)
+        return val if keepdims else np.squeeze(val, axis=axis)
+
+    def backward(ctx, out_grad):
+        x, val, axis, keepdims = ctx.get_saved_tensors()
+        if not keepdims:
+            out_grad = np.expand_dims(out_grad, axis=axis)
+        return out_grad * (x == val)
+
+
+@_op()
+class min(Function):
+    """ cpu/ops.py:274-286 """
+    def forward(ctx, x, axis=None, keepdims=False):
+        axis = _all_axes(x, axis)
+        val = np.min(x, axis=axis, keepdims=True)
+        ctx.save_for_backward(x, val, axis, keepdims)
+        return val if keepdims else np.squeeze(val, axis=axis)
+
+    def backward(ctx, out_grad):
+        x, val, axis, keepdims = ctx.get_saved_tensors()
+        if not keepdims:
+            out_grad = np.expand_dims(out_grad, axis=axis)
+        return out_grad * (x == val)
+
+
+@_op()
+class sum(Function):
+    """ forward = ndarray.sum (cpu/ops.py:288-293); backward = gradient broadcast back to
+    the input shape, the semantics of the reference's only sum.backward (opencl/ops.py:353-368) """
+    def forward(ctx, t, axis=None, keepdims=False):
+        ctx.save_for_backward(t.shape, axis, keepdims)
+        return np.asarray(t.sum(axis=axis, keepdims=keepdims))
+
+    def backward(ctx, out_grad):
+        shape, axis, keepdims = ctx.get_saved_tensors()
+        if not keepdims:
+            axes = tuple(range(len(shape))) if axis is None else (axis if isinstance(axis, tuple) else (axis,))
+            axes = tuple(sorted(a % len(shape) for a in axes))
+            out_grad = np.expand_dims(out_grad, axis=axes) if len(shape) > 0 else out_grad
+        return np.broadcast_to(out_grad, shape)

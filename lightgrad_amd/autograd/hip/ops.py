@@ -1,0 +1,646 @@
+"""Ops of the HipTensor backend: each `Function` is a thin host wrapper that
+computes shapes/strides and enqueues hand-written gfx950 kernels through the
+C ABI (include/lghip.h).  Registered names and forward/backward semantics follow
+the reference's backends op by op (cpu/ops.py = numeric ground truth,
+opencl/ops.py = view semantics); citations per class.
+
+Nothing here synchronises with the device and nothing falls back to numpy.
+"""
+import ctypes
+import numpy as np
+from ..func import Function
+from .tensor import HipTensor, HipBuffer, contiguous_strides
+from . import lib as _l
+from .lib import i64
+
+_F32 = np.dtype(np.float32)
+_NULL = None
+
+
+def _is_scalar(x):
+    return isinstance(x, (int, float, np.integer, np.floating)) or (isinstance(x, np.ndarray) and x.ndim == 0)
+
+
+def _require_f32(*tensors):
+    for t in tensors:
+        if isinstance(t, HipTensor) and t.dtype != _F32:
+            raise TypeError("HipTensor arithmetic is float32-only (got %s); layout ops accept any dtype" % t.dtype)
+
+
+def _broadcast_shapes(*shapes):
+    nd = max(len(s) for s in shapes)
+    out = [1] * nd
+    for s in shapes:
+        for i, d in enumerate(s):
+            j = nd - len(s) + i
+            if d != 1:
+                if out[j] != 1 and out[j] != d:
+                    raise ValueError("operands could not be broadcast together with shapes %s" % (shapes,))
+                out[j] = d
+    return tuple(out)
+
+
+def _bstrides(t, shape):
+    """strides of `t` viewed as `shape` (numpy broadcasting: missing / size-1 dims get stride 0)"""
+    if t._shape == shape:
+        return t._strides
+    lead = len(shape) - len(t._shape)
+    return (0,) * lead + tuple(0 if s == 1 and o != 1 else st for s, st, o in zip(t._shape, t._strides, shape[lead:]))
+
+
+def _ew(op, shape, ins, scalar=0.0, n_out=1, out=None):
+    """enqueue one lg_ew call; `ins` holds HipTensors or None (= the scalar operand)"""
+    L = _l.lib()
+    outs = [out] if out is not None else [HipTensor.empty(shape) for _ in range(n_out)]
+    args = []
+    for k in range(4):
+        t = ins[k] if k < len(ins) else None
+        if t is None:
+            args += [_NULL, _NULL]
+        else:
+            args += [t.ptr, i64(_bstrides(t, shape))]
+    o1 = outs[1] if len(outs) > 1 else None
+    _l.check(L.lg_ew(op, len(shape), i64(shape), outs[0].ptr, i64(outs[0]._strides),
+                     o1.ptr if o1 is not None else _NULL, i64(o1._strides) if o1 is not None else _NULL,
+                     *args, float(scalar)))
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+def _unary(op, t):
+    _require_f32(t)
+    return _ew(op, t._shape, [t])
+
+
+def _binary(op, a, b, out=None):
+    """a (op) b with numpy broadcasting; either operand (not both) may be a python/numpy scalar"""
+    _require_f32(a, b)
+    if _is_scalar(b):
+        return _ew(op, a._shape, [a, None], scalar=b, out=out)
+    if _is_scalar(a):
+        return _ew(op, b._shape, [None, b], scalar=a, out=out)
+    shape = a._shape if a._shape == b._shape else _broadcast_shapes(a._shape, b._shape)
+    return _ew(op, shape, [a, b], out=out)
+
+
+def _alias(t):
+    """new tensor object on the same storage (what in-place ops return, cf. cpu/ops.py:120-146)"""
+    return HipTensor(t.data, t._shape, t._strides, t._offset, t._dtype, requires_grad=t.requires_grad)
+
+
+""" Transformations """
+
+
+@HipTensor.register_op()
+@HipTensor.register_op("T")
+class transpose(Function):
+    """ stride permutation, no data movement (opencl/ops.py:9-27; numpy semantics cpu/ops.py:25-36) """
+    def forward(ctx, a, *axes):
+        if len(axes) == 0:
+            axes = tuple(reversed(range(len(a._shape))))
+        assert len(axes) == len(a._shape)
+        axes = tuple(ax % len(axes) for ax in axes)
+        ctx.save_for_backward(axes)
+        return HipTensor(a.data, tuple(a._shape[i] for i in axes), tuple(a._strides[i] for i in axes), a._offset, a._dtype)
+
+    def backward(ctx, out_grad):
+        axes, = ctx.get_saved_tensors()
+        inverse = [0] * len(axes)
+        for i, j in enumerate(axes):
+            inverse[j] = i
+        return out_grad.transpose(*inverse)
+
+
+@HipTensor.register_op()
+class reshape(Function):
+    """ view when the tensor is dense, gathered copy otherwise (opencl/ops.py:29-36, cpu/ops.py:38-47) """
+    def forward(ctx, a, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        ctx.save_for_backward(a._shape)
+        n = a.numel()
+        if -1 in shape:
+            known = 1
+            for s in shape:
+                if s != -1:
+                    known *= s
+            shape = tuple((n // known if known else 0) if s == -1 else s for s in shape)
+        m = 1
+        for s in shape:
+            m *= s
+        if m != n:
+            raise ValueError("cannot reshape tensor of size %d into shape %s" % (n, shape))
+        src = a.contiguous()
+        return HipTensor(src.data, shape, None, src._offset, a._dtype)
+
+    def backward(ctx, out_grad):
+        shape, = ctx.get_saved_tensors()
+        return out_grad.reshape(*shape)
+
+
+""" Basic math """
+
+
+@HipTensor.register_op()
+class neg(Function):
+    """ cpu/ops.py:52-58 """
+    def forward(ctx, a):
+        return _unary(_l.EW_NEG, a)
+
+    def backward(ctx, out_grad):
+        return _unary(_l.EW_NEG, out_grad)
+
+
+@HipTensor.register_op()
+class add(Function):
+    """ cpu/ops.py:60-66 """
+    def forward(ctx, a, b):
+        return _binary(_l.EW_ADD, a, b)
+
+    def backward(ctx, out_grad):
+        return out_grad, out_grad
+
+
+@HipTensor.register_op(overwrite=True)
+class sub(Function):
+    """ cpu/ops.py:68-74 """
+    def forward(ctx, a, b):
+        return _binary(_l.EW_SUB, a, b)
+
+    def backward(ctx, out_grad):
+        return out_grad, _unary(_l.EW_NEG, out_grad)
+
+
+@HipTensor.register_op()
+class mul(Function):
+    """ cpu/ops.py:76-84; tensor*tensor backward is one two-output kernel (opencl/ops.py:78-83) """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _binary(_l.EW_MUL, a, b)
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        if _is_scalar(b):
+            return _binary(_l.EW_MUL, out_grad, b)
+        if _is_scalar(a):
+            return None, _binary(_l.EW_MUL, out_grad, a)
+        _require_f32(a, b, out_grad)
+        shape = _broadcast_shapes(a._shape, b._shape, out_grad._shape)
+        return _ew(_l.EW_MUL_BWD, shape, [a, b, out_grad], n_out=2)
+
+
+@HipTensor.register_op(overwrite=True)
+class div(Function):
+    """ cpu/ops.py:86-94 """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _binary(_l.EW_DIV, a, b)
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        if _is_scalar(b):
+            return _binary(_l.EW_DIV, out_grad, b)
+        if _is_scalar(a):
+            # -a / b**2 * g, evaluated left to right like the numpy expression
+            t = _binary(_l.EW_DIV, -float(a), _binary(_l.EW_MUL, b, b))
+            return None, _binary(_l.EW_MUL, t, out_grad)
+        _require_f32(a, b, out_grad)
+        shape = _broadcast_shapes(a._shape, b._shape, out_grad._shape)
+        return _ew(_l.EW_DIV_BWD, shape, [a, b, out_grad], n_out=2)
+
+
+def _pow_scalar(a, e):
+    """a ** e for a scalar exponent, with numpy's scalar fast paths (square, sqrt, reciprocal, identity)"""
+    e = float(e)
+    if e == 2.0:
+        return _binary(_l.EW_MUL, a, a)
+    if e == 1.0:
+        return _unary(_l.EW_COPY, a)
+    if e == 0.5:
+        return _unary(_l.EW_SQRT, a)
+    if e == -1.0:
+        return _binary(_l.EW_DIV, 1.0, a)
+    return _binary(_l.EW_POW, a, e)
+
+
+@HipTensor.register_op()
+class pow(Function):
+    """ cpu/ops.py:96-105 """
+    def forward(ctx, a, b):
+        y = _pow_scalar(a, b) if _is_scalar(b) else _binary(_l.EW_POW, a, b)
+        ctx.save_for_backward(a, b, y)
+        return y
+
+    def backward(ctx, out_grad):
+        a, b, y = ctx.get_saved_tensors()
+        if _is_scalar(b):
+            # b * a**(b-1) * g
+            return _binary(_l.EW_MUL, _binary(_l.EW_MUL, _pow_scalar(a, float(b) - 1.0), b), out_grad)
+        if _is_scalar(a):
+            # g * y * log(a)
+            return None, _binary(_l.EW_MUL, _binary(_l.EW_MUL, out_grad, y), float(np.log(np.float32(a))))
+        _require_f32(a, b, out_grad)
+        shape = _broadcast_shapes(a._shape, b._shape, out_grad._shape)
+        return _ew(_l.EW_POW_BWD, shape, [a, b, out_grad, y], n_out=2)
+
+
+""" Matrix product """
+
+
+class _Mat(object):
+    """2-D (optionally batched) operand as the GEMM sees it: pointer + which index is contiguous + ld"""
+    __slots__ = ("t", "rows", "cols", "colmajor", "ld")
+
+    def __init__(self, t, rows, cols, sr, sc):
+        if cols == 1 or sc == 1:
+            self.colmajor, self.ld, self.t = False, max(sr, cols) if rows > 1 else cols, t
+        elif rows == 1 or sr == 1:
+            self.colmajor, self.ld, self.t = True, max(sc, rows) if cols > 1 else rows, t
+        else:
+            raise ValueError("not a GEMM operand layout")
+        self.rows, self.cols = rows, cols
+
+
+def _as_mat(t):
+    """(tensor to keep alive, _Mat) for the last two dims of t; copies only if neither dim is unit-stride"""
+    rows, cols = t._shape[-2], t._shape[-1]
+    sr, sc = t._strides[-2], t._strides[-1]
+    ok = (cols == 1 or sc == 1) and (rows == 1 or sr >= cols) or (rows == 1 or sr == 1) and (cols == 1 or sc >= rows)
+    if not ok:
+        t = t.contiguous()
+        sr, sc = t._strides[-2], t._strides[-1]
+    return _Mat(t, rows, cols, sr, sc)
+
+
+def _collapse_batch(shape, strides):
+    """(count, stride) if the batch dims walk as one strided run, else None"""
+    dims = [(s, st) for s, st in zip(shape, strides) if s != 1]
+    if not dims:
+        return 1, 0
+    n, st = dims[-1]
+    for s, sst in reversed(dims[:-1]):
+        if sst != st * n:
+            return None
+        n *= s
+    return n, st
+
+
+def _gemm(a, b, out_colmajor=False):
+    """a (..., M, K) @ b (..., K, N) -> (..., M, N) on the MFMA SGEMM kernel.
+
+    Operands are consumed in place whenever one of their last two dims has stride 1
+    (row-major or stride-permuted views alike).  `out_colmajor` stores the result
+    transposed in memory and returns the matching view, so that a gradient can be
+    produced directly in the layout of the tensor it belongs to.
+    """
+    _require_f32(a, b)
+    squeeze_a = squeeze_b = False
+    if len(a._shape) == 1:
+        a, squeeze_a = a.reshape(1, a._shape[0]), True
+    if len(b._shape) == 1:
+        b, squeeze_b = b.reshape(b._shape[0], 1), True
+    M, K = a._shape[-2], a._shape[-1]
+    K2, N = b._shape[-2], b._shape[-1]
+    if K != K2:
+        raise ValueError("matmul: shapes %s and %s do not align" % (a._shape, b._shape))
+    batch_shape = _broadcast_shapes(a._shape[:-2], b._shape[:-2]) if (len(a._shape) > 2 or len(b._shape) > 2) else ()
+
+    # (B..., M, K) @ (K, N) with dense leading dims is ONE tall GEMM
+    if len(b._shape) == 2 and len(a._shape) > 2:
+        lead = _collapse_batch(a._shape[:-1], a._strides[:-1])
+        if lead is None or not (a._strides[-1] == 1 or K == 1):
+            a = a.contiguous()
+            lead = _collapse_batch(a._shape[:-1], a._strides[:-1])
+        rows, rstride = lead
+        flat = HipTensor(a.data, (rows, K), (rstride if rows > 1 else K, a._strides[-1]), a._offset, a._dtype)
+        out = _gemm(flat, b, out_colmajor=False)
+        return out.reshape(*batch_shape, M, N)
+
+    ma, mb = _as_mat(a), _as_mat(b)
+    a, b = ma.t, mb.t
+    nb = 1
+    for s in batch_shape:
+        nb *= s
+    out_shape = batch_shape + (M, N)
+    if out_colmajor:
+        out = HipTensor.empty(batch_shape + (N, M))
+    else:
+        out = HipTensor.empty(out_shape)
+
+    def batch_layout(t):
+        bs = _bstrides(HipTensor(t.data, t._shape[:-2], t._strides[:-2], t._offset, t._dtype), batch_shape) if batch_shape else ()
+        return bs
+
+    sa, sb = batch_layout(a), batch_layout(b)
+    so = contiguous_strides(batch_shape + (1,))[:-1] if batch_shape else ()
+    so = tuple(s * M * N for s in so)
+
+    L = _l.lib()
+
+    def launch(pa, pb, po, count, stra, strb, stro):
+        if out_colmajor:
+            # C^T (N x M, row-major) = B^T @ A^T : swap the operands and flip their layouts
+            _l.check(L.lg_gemm_f32(0 if mb.colmajor else 1, 0 if ma.colmajor else 1, N, M, K,
+                                   pb, mb.ld, strb, pa, ma.ld, stra, po, M, stro, count, 0))
+        else:
+            _l.check(L.lg_gemm_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
+                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, 0))
+
+    if nb > 0 and M > 0 and N > 0:
+        ca, cb = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb)
+        if ca is not None and cb is not None:
+            launch(a.ptr, b.ptr, out.ptr, nb, ca[1], cb[1], M * N)
+        else:
+            # batch dims that do not collapse (e.g. attention heads split by a transpose): loop over the
+            # leading dims, batch the innermost one
+            inner = batch_shape[-1]
+            for idx in np.ndindex(*batch_shape[:-1]):
+                oa = sum(i * s for i, s in zip(idx, sa[:-1])) * 4
+                ob = sum(i * s for i, s in zip(idx, sb[:-1])) * 4
+                oo = sum(i * s for i, s in zip(idx, so[:-1])) * 4
+                launch(a.ptr + oa, b.ptr + ob, out.ptr + oo, inner, sa[-1], sb[-1], M * N)
+    if out_colmajor:
+        nd = len(out_shape)
+        out = HipTensor(out.data, out_shape, out._strides[:-2] + (1, M), out._offset, out._dtype)
+        assert nd == len(out._strides)
+    if squeeze_a:
+        out = out.reshape(*out._shape[:-2], out._shape[-1])
+    if squeeze_b:
+        out = out.reshape(*out._shape[:-1])
+    return out
+
+
+def _is_colmajor(t):
+    return len(t._shape) >= 2 and t._strides[-2] == 1 and t._shape[-1] > 1 and t._strides[-1] != 1
+
+
+def _swap_last(t):
+    return HipTensor(t.data, t._shape[:-2] + (t._shape[-1], t._shape[-2]), t._strides[:-2] + (t._strides[-1], t._strides[-2]),
+                     t._offset, t._dtype)
+
+
+@HipTensor.register_op()
+@HipTensor.register_op("__matmul__")
+class dot(Function):
+    """ a @ b (cpu/ops.py:107-116); backward g @ b^T, a^T @ g with the last two axes swapped so it is
+    also right for batched operands (opencl/ops.py:127-132).  Transposed operands are views; each
+    gradient is produced in the memory layout of the operand it belongs to, so `W.T(1,0)` in
+    nn.Linear gets a gradient that transposes back to a dense dW without a strided accumulate. """
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _gemm(a, b)
+
+    def backward(ctx, out_grad):
+        a, b = ctx.get_saved_tensors()
+        if len(a._shape) < 2 or len(b._shape) < 2:
+            # vector operands: fall back to explicit 2-D views
+            a2 = a.reshape(1, -1) if len(a._shape) == 1 else a
+            b2 = b.reshape(-1, 1) if len(b._shape) == 1 else b
+            g2 = out_grad.reshape(*a2._shape[:-1], b2._shape[-1])
+            ga = _gemm(g2, _swap_last(b2)).reshape(*a._shape)
+            gb = _gemm(_swap_last(a2), g2).reshape(*b._shape)
+            return ga, gb
+        if len(b._shape) == 2 and len(a._shape) > 2:
+            # (B..., M, K) @ (K, N): dB = a_flat^T @ g_flat in one GEMM (no per-batch products + reduction)
+            K, N = b._shape
+            a_flat, g_flat = a.reshape(-1, K), out_grad.reshape(-1, N)
+            ga = _gemm(g_flat, _swap_last(b), out_colmajor=False).reshape(*a._shape)
+            gb = _gemm(_swap_last(a_flat), g_flat, out_colmajor=_is_colmajor(b))
+            return ga, gb
+        ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
+        gb = _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
+        return ga, gb
+
+
+""" In-place operators: no backward; the result aliases the input storage (cpu/ops.py:120-153) """
+
+
+def _inplace(op, t, other):
+    if isinstance(other, HipTensor):
+        assert _broadcast_shapes(t._shape, other._shape) == t._shape, \
+            "in-place operand of shape %s does not broadcast to %s" % (other._shape, t._shape)
+    _binary(op, t, other, out=t)
+    return _alias(t)
+
+
+@HipTensor.register_op("__iadd__", overwrite=True)
+class iadd(Function):
+    def forward(ctx, t, other):
+        return _inplace(_l.EW_ADD, t, other)
+
+
+@HipTensor.register_op("__isub__", overwrite=True)
+class isub(Function):
+    def forward(ctx, t, other):
+        return _inplace(_l.EW_SUB, t, other)
+
+
+@HipTensor.register_op("__imul__", overwrite=True)
+class imul(Function):
+    def forward(ctx, t, other):
+        return _inplace(_l.EW_MUL, t, other)
+
+
+@HipTensor.register_op("__itruediv__", overwrite=True)
+class itruediv(Function):
+    def forward(ctx, t, other):
+        return _inplace(_l.EW_DIV, t, other)
+
+
+def _value_bits(val, dtype):
+    raw = np.asarray(val).astype(dtype).tobytes()
+    return int.from_bytes(raw, "little")
+
+
+@HipTensor.register_op()
+class fill(Function):
+    """ opencl/ops.py:172-177; works on strided views and any dtype """
+    def forward(ctx, t, val):
+        _l.check(_l.lib().lg_fill_strided(t._dtype.itemsize, len(t._shape), i64(t._shape), t.ptr, i64(t._strides),
+                                          _value_bits(val, t._dtype)))
+        return t
+
+
+""" Non-linearities """
+
+
+def _unary_op(name, fwd, bwd, save_output, cite):
+    class Op(Function):
+        def forward(ctx, t):
+            y = _unary(fwd, t)
+            ctx.save_for_backward(y if save_output else t)
+            return y
+
+        def backward(ctx, out_grad):
+            s, = ctx.get_saved_tensors()
+            return _binary(bwd, s, out_grad)
+    Op.__name__ = Op.__qualname__ = name
+    Op.__doc__ = cite
+    return Op
+
+
+# exp saves its output (y * g), sigmoid/tanh too; sin/cos/log/relu save the input
+exp = HipTensor.register_op("exp", _unary_op("exp", _l.EW_EXP, _l.EW_MUL, True, "cpu/ops.py:178-187"))
+log = HipTensor.register_op("log", _unary_op("log", _l.EW_LOG, _l.EW_LOG_BWD, False, "cpu/ops.py:189-197"))
+sin = HipTensor.register_op("sin", _unary_op("sin", _l.EW_SIN, _l.EW_SIN_BWD, False, "cpu/ops.py:158-166"))
+cos = HipTensor.register_op("cos", _unary_op("cos", _l.EW_COS, _l.EW_COS_BWD, False, "cpu/ops.py:168-176"))
+sigmoid = HipTensor.register_op("sigmoid", _unary_op("sigmoid", _l.EW_SIGMOID, _l.EW_SIGMOID_BWD, True, "cpu/ops.py:199-208"),
+                                overwrite=True)
+tanh = HipTensor.register_op("tanh", _unary_op("tanh", _l.EW_TANH, _l.EW_TANH_BWD, True, "cpu/ops.py:210-219"), overwrite=True)
+relu = HipTensor.register_op("relu", _unary_op("relu", _l.EW_RELU, _l.EW_RELU_BWD, False,
+                                               "gradient passes at exactly 0: g * (t >= 0) (cpu/ops.py:221-229)"))
+
+
+""" Selectors """
+
+
+def _idx_view(a, idx):
+    """basic indexing (ints, slices, Ellipsis, None) as a strided view (opencl/ops.py:299-313, plus steps)"""
+    idx = idx if isinstance(idx, tuple) else (idx,)
+    if any(isinstance(i, (list, np.ndarray, HipTensor, range)) for i in idx):
+        raise NotImplementedError("HipTensor supports basic indexing only (ints, slices, Ellipsis, None); "
+                                  "index on a CpuTensor and move the result with .hip()")
+    n_real = sum(1 for i in idx if i is not None and i is not Ellipsis)
+    if Ellipsis in idx:
+        k = idx.index(Ellipsis)
+        idx = idx[:k] + (slice(None),) * (len(a._shape) - n_real) + idx[k + 1:]
+    else:
+        idx = idx + (slice(None),) * (len(a._shape) - n_real)
+    shape, strides, offset, d = [], [], a._offset, 0
+    for i in idx:
+        if i is None:
+            shape.append(1)
+            strides.append(0)
+            continue
+        size, st = a._shape[d], a._strides[d]
+        if isinstance(i, slice):
+            start, stop, step = i.indices(size)
+            n = len(range(start, stop, step))
+            shape.append(n)
+            strides.append(st * step)
+            offset += start * st
+        else:
+            i = int(i)
+            if i < -size or i >= size:
+                raise IndexError("index %d is out of bounds for axis %d with size %d" % (i, d, size))
+            offset += (i % size) * st
+        d += 1
+    return HipTensor(a.data, tuple(shape), tuple(strides), offset, a._dtype)
+
+
+@HipTensor.register_op("__getitem__")
+class getitem(Function):
+    """ view + dense copy (opencl/ops.py:315-329); backward scatters into zeros (cpu/ops.py:242-246) """
+    def forward(ctx, a, idx):
+        ctx.save_for_backward(a._shape, idx)
+        return _idx_view(a, idx).copy()
+
+    def backward(ctx, out_grad):
+        shape, idx = ctx.get_saved_tensors()
+        grad = HipTensor.zeros(shape, dtype=out_grad._dtype, requires_grad=False)
+        grad[idx] = out_grad
+        return grad
+
+
+@HipTensor.register_op("__setitem__")
+class setitem(Function):
+    """ strided copy / fill into the indexed view (opencl/ops.py:331-340) """
+    def forward(ctx, a, idx, val):
+        view = _idx_view(a, idx)
+        if isinstance(val, np.ndarray) and val.ndim > 0:
+            val = HipTensor.from_numpy(val.astype(a._dtype), requires_grad=False)
+        if isinstance(val, HipTensor):
+            assert val._dtype == a._dtype, "setitem: dtype mismatch (%s <- %s)" % (a._dtype, val._dtype)
+            assert _broadcast_shapes(view._shape, val._shape) == view._shape, \
+                "setitem: value of shape %s does not broadcast to %s" % (val._shape, view._shape)
+            _l.check(_l.lib().lg_copy_strided(a._dtype.itemsize, len(view._shape), i64(view._shape), view.ptr,
+                                              i64(view._strides), val.ptr, i64(_bstrides(val, view._shape))))
+        else:
+            view.fill(val)
+        return a
+
+
+""" Reductions """
+
+
+def _norm_axes(nd, axis):
+    if axis is None:
+        return tuple(range(nd))
+    axes = axis if isinstance(axis, (tuple, list)) else (axis,)
+    axes = tuple(sorted(a % nd for a in axes)) if nd > 0 else ()
+    assert len(set(axes)) == len(axes), "duplicate value in 'axis'"
+    return axes
+
+
+def _reduce(op, x, axes, keepdims):
+    _require_f32(x)
+    mask = 0
+    for a in axes:
+        mask |= 1 << a
+    kept = tuple(s for i, s in enumerate(x._shape) if i not in axes)
+    out = HipTensor.empty(kept)
+    _l.check(_l.lib().lg_reduce(op, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, out.ptr))
+    if keepdims:
+        full = tuple(1 if i in axes else s for i, s in enumerate(x._shape))
+        out = HipTensor(out.data, full, None, out._offset, out._dtype)
+    return out
+
+
+def _keepdims_view(t, in_shape, axes, keepdims):
+    """view of a reduced tensor with the reduced axes re-inserted as size-1 dims"""
+    if keepdims:
+        return t
+    full = tuple(1 if i in axes else s for i, s in enumerate(in_shape))
+    it = iter(t._strides)
+    strides = tuple(0 if i in axes else next(it) for i in range(len(in_shape)))
+    return HipTensor(t.data, full, strides, t._offset, t._dtype)
+
+
+@HipTensor.register_op()
+class sum(Function):
+    """ forward cpu/ops.py:288-293; backward = zero-stride broadcast VIEW of the gradient, no kernel
+    (the reference's only sum.backward: opencl/ops.py:353-368) """
+    def forward(ctx, x, axis=None, keepdims=False):
+        axes = _norm_axes(len(x._shape), axis)
+        ctx.save_for_backward(x._shape, axes, keepdims)
+        return _reduce(_l.RED_SUM, x, axes, keepdims)
+
+    def backward(ctx, out_grad):
+        shape, axes, keepdims = ctx.get_saved_tensors()
+        g = _keepdims_view(out_grad, shape, axes, keepdims)
+        return HipTensor(g.data, shape, _bstrides(g, shape), g._offset, g._dtype)
+
+
+def _extremum(name, red_op, cite):
+    class Op(Function):
+        def forward(ctx, x, axis=None, keepdims=False):
+            axes = _norm_axes(len(x._shape), axis)
+            val = _reduce(red_op, x, axes, True)
+            ctx.save_for_backward(x, val, axes, keepdims)
+            if keepdims:
+                return val
+            return HipTensor(val.data, tuple(s for i, s in enumerate(x._shape) if i not in axes), None, val._offset, val._dtype)
+
+        def backward(ctx, out_grad):
+            x, val, axes, keepdims = ctx.get_saved_tensors()
+            g = _keepdims_view(out_grad, x._shape, axes, keepdims)
+            _require_f32(out_grad)
+            return _ew(_l.EW_MAX_BWD, x._shape, [x, val, g])
+    Op.__name__ = Op.__qualname__ = name
+    Op.__doc__ = cite
+    return Op
+
+
+max = HipTensor.register_op("max", _extremum("max", _l.RED_MAX, "every tied maximum receives the gradient: g * (x == max) (cpu/ops.py:260-272)"))
+min = HipTensor.register_op("min", _extremum("min", _l.RED_MIN, "cpu/ops.py:274-286"))
+
+
+""" Fused forms used by nn / optim (SURVEY.md §8f row 1) """
+
+
+def adam_step_(p, g, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, gscale=1.0, belief=False):
+    """in-place fused Adam/AdaBelief update of dense fp32 tensors (lg_adam_step_f32)"""
+    _require_f32(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.is_contiguous() and t._shape == p._shape, "adam_step_ needs dense tensors of one shape"
+    _l.check(_l.lib().lg_adam_step_f32(p.ptr, g.ptr, m.ptr, v.ptr, p.numel(), lr, b1, b2, eps, inv_bias1, inv_bias2, gscale,
+                                       1 if belief else 0))

@@ -1,0 +1,201 @@
+"""HipTensor: strided device tensor on an MI355X, the backend this repo adds
+next to CpuTensor.
+
+Same shape as the reference's OpenCLTensor (opencl/tensor.py:18-116): a device
+buffer plus shape / strides (in elements) / offset, so `transpose` and basic
+`__getitem__` views are stride arithmetic and never move data.  Differences by
+design: memory comes from liblghip's caching stream-ordered pool, every
+operation is asynchronous on one HIP stream (only `numpy()`/`item()` block),
+and scalar results have shape `()` like the CPU backend (the reference's OpenCL
+tensor coerces `()` to `(1,)`, opencl/tensor.py:35).
+
+There is no CPU fallback anywhere in this class: without liblghip.so and a GPU
+every constructor raises `HipError`.
+"""
+import ctypes
+import numpy as np
+from ..tensor import AbstractTensor
+from . import lib as _l
+
+
+def contiguous_strides(shape):
+    strides, acc = [], 1
+    for s in reversed(shape):
+        strides.append(acc)
+        acc *= s
+    return tuple(reversed(strides))
+
+
+class HipBuffer(object):
+    """Owner of one pool allocation; returned to the pool when the last tensor viewing it dies."""
+    __slots__ = ("ptr", "nbytes", "__weakref__")
+
+    def __init__(self, nbytes):
+        self.ptr = None
+        p = ctypes.c_void_p()
+        _l.check(_l.lib().lg_malloc(ctypes.byref(p), max(int(nbytes), 1)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        ptr, self.ptr = self.ptr, None
+        if ptr is not None and _l._lib is not None:
+            _l._lib.lg_free(ptr)
+
+
+class HipDevice(object):
+    """The GPU this process is bound to (one process per GPU; reference analog: OpenCLDevice,
+    opencl/device.py:68-115 - context + in-order queue + memory pool)."""
+
+    @staticmethod
+    def is_available() -> bool:
+        try:
+            _l.lib()
+            return True
+        except (_l.HipError, OSError):
+            return False
+
+    @staticmethod
+    def info() -> dict:
+        di = _l.DeviceInfo()
+        _l.check(_l.lib().lg_device_info(ctypes.byref(di)))
+        return {"name": di.name.decode(), "arch": di.arch.decode(), "compute_units": di.compute_units,
+                "clock_mhz": di.clock_mhz, "wavefront_size": di.wavefront_size,
+                "lds_bytes_per_cu": di.lds_bytes_per_cu, "hbm_bytes": di.hbm_bytes, "l2_bytes": di.l2_bytes}
+
+    @staticmethod
+    def synchronize() -> None:
+        _l.check(_l.lib().lg_sync())
+
+    @staticmethod
+    def pool_stats() -> dict:
+        r, u, n = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _l.check(_l.lib().lg_pool_stats(ctypes.byref(r), ctypes.byref(u), ctypes.byref(n)))
+        return {"reserved_bytes": r.value, "in_use_bytes": u.value, "hip_malloc_calls": n.value}
+
+    @staticmethod
+    def trim_pool() -> None:
+        _l.check(_l.lib().lg_pool_trim())
+
+
+class HipTensor(AbstractTensor):
+
+    def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
+                 dtype: type = np.float32, requires_grad: bool = True):
+        assert isinstance(buffer, HipBuffer)
+        AbstractTensor.__init__(self, data=buffer, requires_grad=requires_grad)
+        self._dtype = np.dtype(dtype)
+        self._shape = tuple(int(s) for s in shape)
+        self._strides = contiguous_strides(self._shape) if strides is None else tuple(int(s) for s in strides)
+        self._offset = int(offset)
+        assert len(self._shape) == len(self._strides), \
+            "Shapes and strides do not align! (%s <-> %s)" % (self._shape, self._strides)
+        assert len(self._shape) <= 8, "HipTensor supports at most 8 dimensions"
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def shape(self) -> tuple:
+        return self._shape
+
+    @property
+    def strides(self) -> tuple:
+        return self._strides
+
+    @property
+    def offset(self) -> int:
+        return self._offset
+
+    @property
+    def ptr(self) -> int:
+        """device address of element [0, ..., 0]"""
+        return self._data.ptr + self._offset * self._dtype.itemsize
+
+    def numel(self) -> int:
+        n = 1
+        for s in self._shape:
+            n *= s
+        return n
+
+    """ Initializers """
+
+    @staticmethod
+    def empty(shape, dtype: type = np.float32, requires_grad: bool = True) -> "HipTensor":
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        dtype = np.dtype(dtype)
+        n = 1
+        for s in shape:
+            n *= s
+        return HipTensor(HipBuffer(n * dtype.itemsize), shape=shape, dtype=dtype, requires_grad=requires_grad)
+
+    @staticmethod
+    def zeros(shape, dtype: type = np.float32, requires_grad: bool = True) -> "HipTensor":
+        return HipTensor.empty(shape, dtype, requires_grad).fill(0).detach()
+
+    @staticmethod
+    def ones(shape, dtype: type = np.float32, requires_grad: bool = True) -> "HipTensor":
+        return HipTensor.empty(shape, dtype, requires_grad).fill(1).detach()
+
+    @staticmethod
+    def uniform(low, high, shape, dtype: type = np.float32, requires_grad: bool = True) -> "HipTensor":
+        # drawn on the host exactly like CpuTensor.uniform (float64 draw, then cast: cpu/tensor.py:36-37)
+        # so that both backends start from bit-identical values for the same numpy seed
+        a = np.random.uniform(low, high, size=shape).astype(dtype)
+        return HipTensor.from_numpy(a, requires_grad=requires_grad)
+
+    @staticmethod
+    def from_numpy(a: np.ndarray, requires_grad: bool = True) -> "HipTensor":
+        a = np.ascontiguousarray(a)
+        t = HipTensor.empty(a.shape, dtype=a.dtype, requires_grad=requires_grad)
+        if a.nbytes > 0:
+            _l.check(_l.lib().lg_memcpy_h2d(t.ptr, a.ctypes.data, a.nbytes))
+        return t
+
+    """ Data movement """
+
+    def is_contiguous(self) -> bool:
+        expect = 1
+        for s, st in zip(reversed(self._shape), reversed(self._strides)):
+            if s != 1 and st != expect:
+                return False
+            expect *= s
+        return True
+
+    def contiguous(self) -> "HipTensor":
+        """self if already dense row-major, else a gathered copy (strided copy kernel)"""
+        if self.is_contiguous():
+            return self
+        out = HipTensor.empty(self._shape, dtype=self._dtype, requires_grad=self.requires_grad)
+        nd = len(self._shape)
+        _l.check(_l.lib().lg_copy_strided(self._dtype.itemsize, nd, _l.i64(self._shape), out.ptr, _l.i64(out._strides),
+                                          self.ptr, _l.i64(self._strides)))
+        return out
+
+    def copy(self, requires_grad: bool = True) -> "HipTensor":
+        out = HipTensor.empty(self._shape, dtype=self._dtype, requires_grad=requires_grad)
+        nd = len(self._shape)
+        _l.check(_l.lib().lg_copy_strided(self._dtype.itemsize, nd, _l.i64(self._shape), out.ptr, _l.i64(out._strides),
+                                          self.ptr, _l.i64(self._strides)))
+        return out
+
+    def numpy(self) -> np.ndarray:
+        """blocking device-to-host copy (the only implicit synchronisation point)"""
+        src = self.contiguous()
+        arr = np.empty(self._shape, dtype=self._dtype)
+        if arr.nbytes > 0:
+            _l.check(_l.lib().lg_memcpy_d2h(arr.ctypes.data, src.ptr, arr.nbytes))
+        return arr
+
+    def _fused_adam_step(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief):
+        """optional optimizer hook (optim.Adam(fused=True)): one kernel instead of ~14 elementwise launches"""
+        from .ops import adam_step_
+        adam_step_(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief)
+
+    def __repr__(self):
+        return "HipTensor(shape=%s, strides=%s, dtype=%s)" % (self._shape, self._strides, self._dtype)
+
+
+# registers all hip ops (bottom import: ops needs HipTensor)
+from . import ops  # noqa: E402,F401

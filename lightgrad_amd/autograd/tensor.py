@@ -1,0 +1,191 @@
+"""Backend-independent tensor base: data handle, gradient, tape context,
+op registry and backend registry.
+
+Behavioural restatement of the reference's `lightgrad/autograd/tensor.py`:
+  * `_TensorType` registers a converter `AbstractTensor.<backend>()` for every
+    tensor class defined in a module `<pkg>.autograd.<backend>.tensor`
+    (tensor.py:5-15, :154-161) - this is how `.cpu()` and `.hip()` appear
+  * `backward` seeds `ones(shape)` and only starts from item tensors unless
+    `allow_fill` (tensor.py:99-109)
+  * `add_grad` copies on first touch, `+=` afterwards (tensor.py:111-118)
+  * `zero_grad` allocates zeros or `fill(0)`s the existing gradient and can
+    walk the graph (tensor.py:120-131)
+  * `register_op` installs a dispatching method; refuses non-Functions
+    (TypeError) and silent re-registration (RuntimeError) (tensor.py:136-152)
+"""
+import numpy as np
+from .grads import Gradients
+
+
+class _TensorType(type):
+
+    def __new__(mcs, name, bases, attrs):
+        T = type.__new__(mcs, name, bases, attrs)
+        module = attrs.get('__module__')
+        # classes of this module (the abstract base) and classes minted at run time are skipped
+        if (module is not None) and (module != __name__):
+            parts = module.split('.')
+            if len(parts) >= 2:
+                AbstractTensor.register_backend(parts[-2], T)
+        return T
+
+
+class AbstractTensor(metaclass=_TensorType):
+
+    def __init__(self, data, requires_grad: bool = True) -> None:
+        self._data = data
+        self._grad = None
+        self._requires_grad = requires_grad
+        self._ctx = None
+
+    def _set_ctx(self, ctx) -> "AbstractTensor":
+        assert (ctx is None) or isinstance(ctx, Function)
+        self._ctx = ctx
+        return self
+
+    def _set_data(self, data) -> "AbstractTensor":
+        self._data = data
+        return self
+
+    def detach(self) -> "AbstractTensor":
+        # like the reference this cuts the tape in place (no copy), tensor.py:35-38
+        self._ctx = None
+        return self
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def grad(self) -> "AbstractTensor":
+        return self._grad
+
+    @property
+    def requires_grad(self) -> bool:
+        return self._requires_grad
+
+    @property
+    def dtype(self):
+        raise NotImplementedError()
+
+    @property
+    def shape(self) -> tuple:
+        raise NotImplementedError()
+
+    def item(self):
+        return self.numpy().item()
+
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return int(n)
+
+    """ Initializers """
+
+    @staticmethod
+    def empty(shape, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    @staticmethod
+    def zeros(shape, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    @staticmethod
+    def ones(shape, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    @staticmethod
+    def uniform(low, high, shape, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    @staticmethod
+    def from_numpy(a: np.ndarray, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    @classmethod
+    def xavier(cls, shape, requires_grad: bool = True) -> "AbstractTensor":
+        """U(-1,1) / sqrt(numel), scaled in place (reference tensor.py:85-89)."""
+        t = cls.uniform(-1, 1, shape=shape, requires_grad=requires_grad)
+        t /= np.sqrt(t.numel())
+        return t.detach()
+
+    def copy(self, requires_grad: bool = True) -> "AbstractTensor":
+        raise NotImplementedError()
+
+    def numpy(self) -> np.ndarray:
+        raise NotImplementedError()
+
+    """ Gradients """
+
+    def backward(self, allow_fill: bool = False) -> None:
+        if self._ctx is None:
+            return
+        if self.shape == (1,) or len(self.shape) == 0 or allow_fill:
+            self._grad = self.__class__.ones(self.shape, requires_grad=False)
+        else:
+            raise RuntimeError("Can only backpropagate from item tensors!")
+        Gradients.backward(self._ctx, self._grad)
+
+    def add_grad(self, grad: "AbstractTensor") -> None:
+        if not self._requires_grad:
+            return
+        Gradients.disable()
+        try:
+            if self._grad is None:
+                self._grad = grad.copy(requires_grad=False)
+            else:
+                self._grad += grad
+        finally:
+            Gradients.enable()
+
+    def zero_grad(self, traverse_graph: bool = False) -> None:
+        if self._requires_grad:
+            if self._grad is None:
+                self._grad = self.__class__.zeros(self.shape, requires_grad=False)
+            else:
+                self._grad.fill(0)
+        if traverse_graph and (self._ctx is not None):
+            parents = self._ctx.parent_tensors
+            assert all(t is not self for t in parents)
+            for t in parents:
+                t.zero_grad(traverse_graph=True)
+
+    """ Registration of operations and backends """
+
+    @classmethod
+    def register_op(cls, name: str = None, op: type = None, overwrite: bool = False):
+        if op is None:
+            # decorator form
+            return lambda fn_cls: cls.register_op(name if name is not None else fn_cls.__name__, fn_cls, overwrite=overwrite)
+        if not (isinstance(op, type) and issubclass(op, Function)):
+            raise TypeError("Operators must inherit from Function! (%s)" % getattr(op, '__name__', op))
+        if not overwrite and hasattr(cls, name):
+            raise RuntimeError("Function %s already registered to %s!" % (name, cls.__name__))
+
+        # a plain function attribute binds as a method; the Function class itself would not
+        def dispatch(self, *args, **kwargs):
+            return op(self, *args, **kwargs)
+        dispatch.__name__ = name
+        dispatch.__doc__ = op.__doc__
+        setattr(cls, name, dispatch)
+        return op
+
+    @staticmethod
+    def register_backend(name: str, tensor_cls: type):
+        if not issubclass(tensor_cls, AbstractTensor):
+            raise TypeError("Backend tensors must inherit from Tensor! (%s)" % tensor_cls.__name__)
+
+        def convert(t, *args, **kwargs):
+            return tensor_cls.from_numpy(t.numpy(), *args, **kwargs)
+        convert.__name__ = name
+        setattr(AbstractTensor, name, convert)
+
+
+# bottom imports: func needs AbstractTensor, ops registers the composite operators on it
+from .func import Function  # noqa: E402
+from . import ops  # noqa: E402,F401

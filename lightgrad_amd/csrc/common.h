@@ -1,0 +1,93 @@
+// Internal helpers shared by the translation units of liblghip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/lghip.h"
+
+namespace lg {
+
+// thread-local error text returned by lg_last_error()
+void set_error(const char* fmt, ...);
+
+struct Runtime {
+    bool        ready = false;
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    int         compute_units = 0;
+};
+Runtime& rt();
+
+// true between lg_graph_begin and lg_graph_end
+bool capturing();
+
+}  // namespace lg
+
+#define LG_REQUIRE_INIT()                                                       \
+    do {                                                                        \
+        if (!lg::rt().ready) {                                                  \
+            lg::set_error("%s: lg_init() has not been called", __func__);       \
+            return LG_ENOTINIT;                                                 \
+        }                                                                       \
+    } while (0)
+
+#define LG_HIP(expr)                                                            \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            lg::set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(_e)); \
+            return LG_EHIP;                                                     \
+        }                                                                       \
+    } while (0)
+
+#define LG_CHECK_LAUNCH()                                                       \
+    do {                                                                        \
+        hipError_t _e = hipGetLastError();                                      \
+        if (_e != hipSuccess) {                                                 \
+            lg::set_error("%s: kernel launch failed: %s", __func__, hipGetErrorString(_e)); \
+            return LG_EHIP;                                                     \
+        }                                                                       \
+    } while (0)
+
+#define LG_ARG(cond, ...)                                                       \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            lg::set_error(__VA_ARGS__);                                         \
+            return LG_EINVAL;                                                   \
+        }                                                                       \
+    } while (0)
+
+namespace lg {
+
+// ---- strided iteration descriptor ------------------------------------------
+// Up to NOPS operands over a common (collapsed) index space.  Dimension 0 is the
+// outermost.  Passed to kernels by value (kernarg segment).
+constexpr int kMaxOps = 6;
+
+struct IterDesc {
+    int     ndim;                           // after collapsing, >= 1
+    int64_t numel;
+    int64_t shape[LG_MAX_DIMS];
+    int64_t stride[kMaxOps][LG_MAX_DIMS];   // elements; 0 = broadcast
+};
+
+// Build a collapsed descriptor: drops size-1 dims and merges neighbouring dims that
+// are jointly contiguous for every operand.  strides[i] == nullptr marks an unused
+// operand (its strides become 0).  Returns false if ndim is out of range or any
+// extent is negative.
+bool build_iter(int ndim, const int64_t* shape, const int64_t* const* strides, int nops, IterDesc& out);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// grid size for a grid-stride memory-bound kernel: enough blocks to fill the chip
+// (256 CUs x 8 blocks of 256 threads), never more than the work needs.
+inline unsigned stream_grid(int64_t work_items, int block = 256) {
+    int64_t need = (work_items + block - 1) / block;
+    int64_t cap = 256 * 8;
+    if (need < 1) need = 1;
+    return static_cast<unsigned>(need < cap ? need : cap);
+}
+
+}  // namespace lg

@@ -1,0 +1,332 @@
+// SGEMM on the gfx950 matrix cores: C (+)= op(A) @ op(B), fp32 in / fp32 accumulate,
+// built on v_mfma_f32_32x32x2_f32 (exact fp32 products, 64 FLOP/clk/SIMD = 157.3 TFLOP/s chip peak).
+//
+// Structure (one workgroup = BM x BN tile of C, WM x WN waves, each wave a TM x TN grid of
+// 32x32 MFMA accumulators):
+//   global --float4--> registers --ds_write_b128--> LDS (double buffered) --> fragments --> MFMA
+//   * the next K-tile's global loads are issued BEFORE the MFMAs of the current tile and written
+//     to the other LDS buffer AFTER them: one barrier per K-tile, HBM/L2 latency hidden under
+//     BK/2 * TM * TN MFMAs (64 cycles each).
+//   * operands are consumed in whatever layout the tensor has (A row- or column-major, B row- or
+//     column-major) - no transposition or padding copies.  A "K-contiguous" operand is staged as
+//     [row][BK+4] and a lane fetches FOUR k-values with one ds_read_b128; an "M/N-contiguous"
+//     operand is staged as [BK][rows] and read with conflict-free ds_read_b32.  Both feed the same
+//     MFMA because the k order inside a K-block of 8 is a free choice: MFMA step s (0..3) and
+//     lane half h (0..1) use k = kb + 4h + s for BOTH operands.
+//   * the (BK+4) row pitch makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots
+//     (pitch/4 is odd), i.e. conflict-free without a swizzle.
+//   * workgroup ids are remapped so that the blocks sharing an XCD (ids equal mod 8) work on
+//     neighbouring tiles and share A/B panels in that XCD's L2.
+//   * edges are predicated (zero-filled loads, masked stores): any M, N, K >= 1.
+// Reference semantics: `dot` = numpy matmul (cpu/ops.py:107-116); the tiled OpenCL kernel with its
+// pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
+#include "common.h"
+
+namespace lg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float*       C;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int64_t sA, sB, sC;     // batch strides (elements)
+    int     tiles_m, tiles_n;
+    int     nwg;            // tiles_m * tiles_n * batch
+    int     accumulate;
+};
+
+// blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
+// tile ids.  Bijective for any nwg (cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, pos = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + pos;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
+__global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && BK % 8 == 0, "tile config");
+    constexpr int A_PITCH = AKC ? BK + 4 : BM;          // floats per LDS row
+    constexpr int B_PITCH = BKC ? BK + 4 : BN;
+    constexpr int A_TILE = AKC ? BM * A_PITCH : BK * A_PITCH;
+    constexpr int B_TILE = BKC ? BN * B_PITCH : BK * B_PITCH;
+    constexpr int A_ELEMS = BM * BK / NT, B_ELEMS = BN * BK / NT;   // floats staged per thread
+    static_assert(A_ELEMS % 4 == 0 && B_ELEMS % 4 == 0, "staging must divide into float4");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+    // buffer b: A tile at lds + b*(A_TILE+B_TILE), B tile right behind it
+    constexpr int BUF = A_TILE + B_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // tile coordinates
+    const int id = xcd_remap(blockIdx.x, g.nwg);
+    const int per_batch = g.tiles_m * g.tiles_n;
+    const int batch = id / per_batch;
+    const int t = id - batch * per_batch;
+    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
+    const float* __restrict__ A = g.A + int64_t(batch) * g.sA;
+    const float* __restrict__ B = g.B + int64_t(batch) * g.sB;
+    float* __restrict__ C = g.C + int64_t(batch) * g.sC;
+
+    float ra[A_ELEMS], rb[B_ELEMS];   // staging registers
+
+    auto load_tile = [&](int64_t k0) {
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < A_ELEMS / 4; ++i) {
+                const int f = tid + i * NT;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (AKC) {
+                    const int row = f / (BK / 4), kq = f % (BK / 4);
+                    if (m0 + row < g.M && k0 + kq * 4 < g.K)
+                        v = *reinterpret_cast<const float4*>(A + (m0 + row) * g.lda + k0 + kq * 4);
+                } else {
+                    const int kk = f / (BM / 4), mq = f % (BM / 4);
+                    if (k0 + kk < g.K && m0 + mq * 4 < g.M)
+                        v = *reinterpret_cast<const float4*>(A + (k0 + kk) * g.lda + m0 + mq * 4);
+                }
+                ra[4 * i] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < B_ELEMS / 4; ++i) {
+                const int f = tid + i * NT;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (BKC) {
+                    const int row = f / (BK / 4), kq = f % (BK / 4);
+                    if (n0 + row < g.N && k0 + kq * 4 < g.K)
+                        v = *reinterpret_cast<const float4*>(B + (n0 + row) * g.ldb + k0 + kq * 4);
+                } else {
+                    const int kk = f / (BN / 4), nq = f % (BN / 4);
+                    if (k0 + kk < g.K && n0 + nq * 4 < g.N)
+                        v = *reinterpret_cast<const float4*>(B + (k0 + kk) * g.ldb + n0 + nq * 4);
+                }
+                rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ELEMS; ++i) {
+                const int e = tid + i * NT;
+                float v = 0.f;
+                if constexpr (AKC) {
+                    const int row = e / BK, kk = e % BK;
+                    if (m0 + row < g.M && k0 + kk < g.K) v = A[(m0 + row) * g.lda + k0 + kk];
+                } else {
+                    const int kk = e / BM, mm = e % BM;
+                    if (k0 + kk < g.K && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_ELEMS; ++i) {
+                const int e = tid + i * NT;
+                float v = 0.f;
+                if constexpr (BKC) {
+                    const int row = e / BK, kk = e % BK;
+                    if (n0 + row < g.N && k0 + kk < g.K) v = B[(n0 + row) * g.ldb + k0 + kk];
+                } else {
+                    const int kk = e / BN, nn = e % BN;
+                    if (k0 + kk < g.K && n0 + nn < g.N) v = B[(k0 + kk) * g.ldb + n0 + nn];
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* a = lds + buf * BUF;
+        float* b = lds + buf * BUF + A_TILE;
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < A_ELEMS / 4; ++i) {
+                const int f = tid + i * NT;
+                const float4 v = make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
+                if constexpr (AKC) *reinterpret_cast<float4*>(a + (f / (BK / 4)) * A_PITCH + (f % (BK / 4)) * 4) = v;
+                else               *reinterpret_cast<float4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_ELEMS / 4; ++i) {
+                const int f = tid + i * NT;
+                const float4 v = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
+                if constexpr (BKC) *reinterpret_cast<float4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = v;
+                else               *reinterpret_cast<float4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ELEMS; ++i) {
+                const int e = tid + i * NT;
+                if constexpr (AKC) a[(e / BK) * A_PITCH + (e % BK)] = ra[i];
+                else               a[(e / BM) * A_PITCH + (e % BM)] = ra[i];
+            }
+#pragma unroll
+            for (int i = 0; i < B_ELEMS; ++i) {
+                const int e = tid + i * NT;
+                if constexpr (BKC) b[(e / BK) * B_PITCH + (e % BK)] = rb[i];
+                else               b[(e / BN) * B_PITCH + (e % BN)] = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute_tile = [&](int buf) {
+        const float* a = lds + buf * BUF + (AKC ? (wm * TM * 32 + r) * A_PITCH + 4 * h : (4 * h) * A_PITCH + wm * TM * 32 + r);
+        const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * TN * 32 + r) * B_PITCH + 4 * h : (4 * h) * B_PITCH + wn * TN * 32 + r);
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (AKC) {
+                    const float4 v = *reinterpret_cast<const float4*>(a + i * 32 * A_PITCH + kb);
+                    fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fa[i][s] = a[(kb + s) * A_PITCH + i * 32];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BKC) {
+                    const float4 v = *reinterpret_cast<const float4*>(b + j * 32 * B_PITCH + kb);
+                    fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fb[j][s] = b[(kb + s) * B_PITCH + j * 32];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int64_t nkt = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int64_t kt = 0; kt < nkt; ++kt) {
+        const int cur = int(kt & 1);
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile((kt + 1) * BK);      // in flight during the MFMAs below
+        compute_tile(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + (wn * TN + j) * 32 + r;
+            const int64_t row0 = m0 + (wm * TM + i) * 32 + 4 * h;
+            if (col < g.N) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+                    if (row < g.M) {
+                        float* p = C + row * g.ldc + col;
+                        *p = g.accumulate ? *p + acc[i][j][e] : acc[i][j][e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static void launch_config(const GemmArgs& base, bool akc, bool bkc, bool vec, int64_t batch) {
+    GemmArgs g = base;
+    g.tiles_m = int((g.M + BM - 1) / BM);
+    g.tiles_n = int((g.N + BN - 1) / BN);
+    g.nwg = int(int64_t(g.tiles_m) * g.tiles_n * batch);
+    dim3 grid(g.nwg), block(WM * WN * 64);
+    hipStream_t s = rt().stream;
+#define LG_GEMM_LAUNCH(AK, BKc, V) hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AK, BKc, V>), grid, block, 0, s, g)
+    if (vec) {
+        if (akc && bkc) LG_GEMM_LAUNCH(true, true, true);
+        else if (akc) LG_GEMM_LAUNCH(true, false, true);
+        else if (bkc) LG_GEMM_LAUNCH(false, true, true);
+        else LG_GEMM_LAUNCH(false, false, true);
+    } else {
+        if (akc && bkc) LG_GEMM_LAUNCH(true, true, false);
+        else if (akc) LG_GEMM_LAUNCH(true, false, false);
+        else if (bkc) LG_GEMM_LAUNCH(false, true, false);
+        else LG_GEMM_LAUNCH(false, false, false);
+    }
+#undef LG_GEMM_LAUNCH
+}
+
+}  // namespace lg
+
+using namespace lg;
+
+extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, int64_t strideA,
+                           const float* B, int64_t ldb, int64_t strideB,
+                           float* C, int64_t ldc, int64_t strideC,
+                           int64_t batch, int accumulate) {
+    LG_REQUIRE_INIT();
+    LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
+           (long long)M, (long long)N, (long long)K, (long long)batch);
+    if (M == 0 || N == 0 || batch == 0) return LG_OK;
+    LG_ARG(A && B && C, "lg_gemm_f32: NULL operand");
+    LG_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
+           "lg_gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld for M=%lld N=%lld K=%lld tA=%d tB=%d)",
+           (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, transA, transB);
+    if (K == 0) {
+        if (accumulate) return LG_OK;
+        // empty sum: C = 0
+        int64_t shape[3] = {batch, M, N}, st[3] = {strideC, ldc, 1};
+        return lg_fill_strided(4, 3, shape, C, st, 0);
+    }
+
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.accumulate = accumulate;
+
+    const bool akc = !transA;   // A[m*lda + k]: k is the contiguous index
+    const bool bkc = transB != 0;   // B[n*ldb + k]
+    // float4 staging needs 16-byte aligned rows and whole float4s inside the matrix
+    auto vec_ok = [](const float* p, int64_t ld, int64_t bstride, int64_t contiguous_extent) {
+        return aligned16(p) && ld % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0;
+    };
+    const bool vec = vec_ok(A, lda, strideA, akc ? K : M) && vec_ok(B, ldb, strideB, bkc ? K : N);
+
+    // tile choice: largest tile that still yields enough workgroups for 256 CUs
+    auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+    LG_ARG(nblocks(32, 32) < (int64_t(1) << 30), "lg_gemm_f32: problem too large for one launch");
+    if (N <= 32) {
+        launch_config<64, 32, 32, 2, 1>(g, akc, bkc, vec, batch);
+    } else if (nblocks(128, 128) >= 384 || (M >= 2048 && N >= 2048)) {
+        launch_config<128, 128, 32, 2, 2>(g, akc, bkc, vec, batch);
+    } else {
+        launch_config<64, 64, 32, 2, 2>(g, akc, bkc, vec, batch);
+    }
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

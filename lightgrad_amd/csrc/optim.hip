@@ -1,0 +1,75 @@
+// Fused Adam / AdaBelief update: one pass over p, g, m, v instead of the
+// ~14 elementwise launches of the tape form (reference optim.py:36-40, :48-52).  HBM-bound:
+// 4 reads + 3 writes of 4 B = 28 B per element.
+//
+// The arithmetic is the reference's expression sequence, evaluated per element with one rounding
+// per operation (the library is built with -ffp-contract=off so nothing is fused):
+//   m  = b1*m + (1-b1)*g          v = b2*v + (1-b2)*s^2   (s = g for Adam, g - m for AdaBelief)
+//   p += ((-lr) * (m * c1)) * (1 / ((v * c2)^0.5 + eps))   with c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
+// (the tape's `/` is `a * b**-1`, autograd/ops.py:30-36, hence the reciprocal-then-multiply form)
+#include "common.h"
+
+namespace lg {
+
+struct AdamScalars {
+    float neg_lr, b1, one_minus_b1, b2, one_minus_b2, eps, inv_bias1, inv_bias2, gscale;
+    int   belief, scale_grad;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamScalars& c) {
+    if (c.scale_grad) g = g * c.gscale;
+    m = c.b1 * m + c.one_minus_b1 * g;
+    const float s = c.belief ? g - m : g;
+    v = c.b2 * v + c.one_minus_b2 * (s * s);
+    const float mh = m * c.inv_bias1, vh = v * c.inv_bias2;
+    p = p + (c.neg_lr * mh) * (1.0f / (sqrtf(vh) + c.eps));
+}
+
+__global__ void __launch_bounds__(256) adam_vec4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t nvec, AdamScalars c) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        adam_elem(P.x, G.x, M.x, V.x, c);
+        adam_elem(P.y, G.y, M.y, V.y, c);
+        adam_elem(P.z, G.z, M.z, V.z, c);
+        adam_elem(P.w, G.w, M.w, V.w, c);
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = M;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+}
+
+__global__ void __launch_bounds__(256) adam_scalar(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t begin, int64_t n, AdamScalars c) {
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = begin + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+        adam_elem(p[i], g[i], m[i], v[i], c);
+}
+
+}  // namespace lg
+
+using namespace lg;
+
+extern "C" int lg_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+                                double eps, double inv_bias1, double inv_bias2, double gscale, int belief) {
+    LG_REQUIRE_INIT();
+    LG_ARG(n >= 0, "lg_adam_step_f32: negative length");
+    if (n == 0) return LG_OK;
+    LG_ARG(p && g && m && v, "lg_adam_step_f32: NULL pointer");
+    AdamScalars c;
+    // 1-b1 and 1-b2 are formed in double like the python expression `(1 - self.b1)`, then rounded once
+    // (python float scalars meet fp32 tensors: numpy rounds the double ONCE to fp32 - same here)
+    c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
+    c.eps = float(eps); c.inv_bias1 = float(inv_bias1); c.inv_bias2 = float(inv_bias2); c.gscale = float(gscale); c.belief = belief;
+    c.scale_grad = gscale != 1.0;
+    hipStream_t s = rt().stream;
+    const bool vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
+    const int64_t nvec = vec ? n / 4 : 0;
+    if (nvec > 0) hipLaunchKernelGGL(adam_vec4, dim3(stream_grid(nvec)), dim3(256), 0, s, p, g, m, v, nvec, c);
+    if (nvec * 4 < n)
+        hipLaunchKernelGGL(adam_scalar, dim3(stream_grid(n - nvec * 4)), dim3(256), 0, s, p, g, m, v, nvec * 4, n, c);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

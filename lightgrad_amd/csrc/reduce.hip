@@ -1,0 +1,300 @@
+// fp32 reductions (sum / max / min over an arbitrary set of axes) for gfx950.
+// HBM-bound: algorithmic traffic is 4 B per input element; the kernels keep loads
+// coalesced (16 B per lane where the layout allows) and combine with wave64 shuffles.
+//
+// Two kernels cover every stride pattern:
+//   red_rows : the reduced axes form ONE contiguous run (trailing-axis sums of softmax /
+//              LayerNorm, full reductions).  One wave per output when there are many short
+//              rows; few long rows are split over many workgroups into partials that a
+//              second launch of the same kernel combines.
+//   red_cols : everything else - one thread per OUTPUT element walking the reduced index
+//              space (leading-axis sums such as the bias un-broadcast `sum((1024,512)->(1,512))`
+//              of func.py:50-56: lanes run along the contiguous kept axis, so loads coalesce);
+//              long reductions are split over blockIdx.y into partials.
+// Semantics: opencl/ops.py:344-400 with cpu/ops.py:260-293 as numeric ground truth
+// (max/min exact incl. NaN propagation like np.max; sum is a tree sum in fp32).
+// The multi-pass LDS tree of opencl/kernels.py:344-501 is not reproduced.
+#include "common.h"
+#include <cmath>
+
+namespace lg {
+
+struct RedDesc {
+    int     nk, nr;                       // kept / reduced dims after collapsing (each >= 1)
+    int64_t n_out, rlen;
+    int64_t kshape[LG_MAX_DIMS], kstride[LG_MAX_DIMS];
+    int64_t rshape[LG_MAX_DIMS], rstride[LG_MAX_DIMS];
+};
+
+template <int OP> struct Red;
+template <> struct Red<LG_RED_SUM> {
+    __device__ static float identity() { return 0.0f; }
+    __device__ static float comb(float a, float b) { return a + b; }
+};
+template <> struct Red<LG_RED_MAX> {
+    __device__ static float identity() { return -INFINITY; }
+    __device__ static float comb(float a, float b) { return (a > b || a != a) ? a : b; }
+};
+template <> struct Red<LG_RED_MIN> {
+    __device__ static float identity() { return INFINITY; }
+    __device__ static float comb(float a, float b) { return (a < b || a != a) ? a : b; }
+};
+
+template <int OP>
+__device__ __forceinline__ float wave_reduce(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = Red<OP>::comb(v, __shfl_down(v, off, 64));
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ int64_t kept_offset(const RedDesc& d, int64_t out_idx) {
+    int64_t off = 0;
+    for (int k = d.nk - 1; k >= 0; --k) {
+        int64_t sz = d.kshape[k];
+        off += (out_idx % sz) * d.kstride[k];
+        out_idx /= sz;
+    }
+    return off;
+}
+
+// ---- rows: reduced run is contiguous (rstride[0] == 1, nr == 1) ---------------------------
+// grid.x = ceil(n_out / ROWS_PER_BLOCK) when splits == 1 (one wave per row, 4 rows per block),
+// else grid = (splits, n_out) with the whole block on one row segment.
+template <int OP>
+__global__ void __launch_bounds__(256) red_rows_wave(const float* __restrict__ in, float* __restrict__ out, RedDesc d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    if (row >= d.n_out) return;
+    const float* p = in + kept_offset(d, row);
+    float acc = Red<OP>::identity();
+    const int64_t n = d.rlen;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        const int64_t nv = n / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int64_t i = lane; i < nv; i += 64) {
+            float4 t = p4[i];
+            acc = Red<OP>::comb(acc, Red<OP>::comb(Red<OP>::comb(t.x, t.y), Red<OP>::comb(t.z, t.w)));
+        }
+        for (int64_t i = nv * 4 + lane; i < n; i += 64) acc = Red<OP>::comb(acc, p[i]);
+    } else {
+        for (int64_t i = lane; i < n; i += 64) acc = Red<OP>::comb(acc, p[i]);
+    }
+    acc = wave_reduce<OP>(acc);
+    if (lane == 0) out[row] = acc;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ in, float* __restrict__ partial, RedDesc d,
+                                                      int64_t seg) {
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = blockIdx.y, split = blockIdx.x, splits = gridDim.x;
+    const int64_t begin = split * seg;
+    int64_t end = begin + seg;
+    if (end > d.rlen) end = d.rlen;
+    const float* p = in + kept_offset(d, row);
+    float acc0 = Red<OP>::identity(), acc1 = Red<OP>::identity();
+    // seg is a multiple of 4, so alignment of p decides alignment of the segment
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        const int64_t v0 = begin / 4, v1 = end / 4;
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        int64_t i = v0 + threadIdx.x;
+        for (; i + 256 < v1; i += 512) {
+            float4 s = p4[i], t = p4[i + 256];
+            acc0 = Red<OP>::comb(acc0, Red<OP>::comb(Red<OP>::comb(s.x, s.y), Red<OP>::comb(s.z, s.w)));
+            acc1 = Red<OP>::comb(acc1, Red<OP>::comb(Red<OP>::comb(t.x, t.y), Red<OP>::comb(t.z, t.w)));
+        }
+        for (; i < v1; i += 256) {
+            float4 s = p4[i];
+            acc0 = Red<OP>::comb(acc0, Red<OP>::comb(Red<OP>::comb(s.x, s.y), Red<OP>::comb(s.z, s.w)));
+        }
+        for (int64_t e = v1 * 4 + threadIdx.x; e < end; e += 256) acc1 = Red<OP>::comb(acc1, p[e]);
+    } else {
+        for (int64_t e = begin + threadIdx.x; e < end; e += 256) acc0 = Red<OP>::comb(acc0, p[e]);
+    }
+    float acc = wave_reduce<OP>(Red<OP>::comb(acc0, acc1));
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[row * splits + split] = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
+}
+
+// ---- cols / general: one thread per output element --------------------------------------------
+template <int OP>
+__global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, float* __restrict__ partial, RedDesc d,
+                                                int64_t chunk) {
+    const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (o >= d.n_out) return;
+    const int64_t split = blockIdx.y;
+    const int64_t begin = split * chunk;
+    int64_t end = begin + chunk;
+    if (end > d.rlen) end = d.rlen;
+    const float* p = in + kept_offset(d, o);
+    float a0 = Red<OP>::identity(), a1 = Red<OP>::identity(), a2 = Red<OP>::identity(), a3 = Red<OP>::identity();
+    if (d.nr == 1) {
+        const int64_t rs = d.rstride[0];
+        int64_t r = begin;
+        for (; r + 3 < end; r += 4) {
+            float x0 = p[r * rs], x1 = p[(r + 1) * rs], x2 = p[(r + 2) * rs], x3 = p[(r + 3) * rs];
+            a0 = Red<OP>::comb(a0, x0); a1 = Red<OP>::comb(a1, x1); a2 = Red<OP>::comb(a2, x2); a3 = Red<OP>::comb(a3, x3);
+        }
+        for (; r < end; ++r) a0 = Red<OP>::comb(a0, p[r * rs]);
+    } else {
+        // odometer over the reduced dims, innermost fastest
+        int64_t idx[LG_MAX_DIMS];
+        int64_t rem = begin, off = 0;
+        for (int k = d.nr - 1; k >= 0; --k) {
+            idx[k] = rem % d.rshape[k];
+            rem /= d.rshape[k];
+            off += idx[k] * d.rstride[k];
+        }
+        for (int64_t r = begin; r < end; ++r) {
+            a0 = Red<OP>::comb(a0, p[off]);
+            int k = d.nr - 1;
+            idx[k] += 1;
+            off += d.rstride[k];
+            while (k > 0 && idx[k] == d.rshape[k]) {
+                off -= d.rshape[k] * d.rstride[k];
+                idx[k] = 0;
+                --k;
+                idx[k] += 1;
+                off += d.rstride[k];
+            }
+        }
+    }
+    partial[split * d.n_out + o] = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+}
+
+// ---- host ---------------------------------------------------------------------------------------
+
+// collapse a list of (shape, stride) pairs in place; returns the new count (>= 1)
+static int collapse(int n, int64_t* shp, int64_t* st) {
+    int m = 0;
+    for (int d = 0; d < n; ++d) {
+        if (shp[d] == 1) continue;
+        if (m > 0 && st[m - 1] == st[d] * shp[d]) {
+            shp[m - 1] *= shp[d];
+            st[m - 1] = st[d];
+        } else {
+            shp[m] = shp[d];
+            st[m] = st[d];
+            ++m;
+        }
+    }
+    if (m == 0) { shp[0] = 1; st[0] = 0; m = 1; }
+    return m;
+}
+
+template <int OP>
+static int run_reduce(const float* in, float* out, RedDesc& d) {
+    hipStream_t s = rt().stream;
+    const bool rows = (d.nr == 1) && (d.rstride[0] == 1 || d.rlen == 1);
+    if (rows) {
+        // many rows, or short rows: a wave per row
+        if (d.n_out >= 256 || d.rlen <= 8192) {
+            hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, in, out, d);
+            return LG_OK;
+        }
+        // few long rows: split each row over enough blocks to fill the chip
+        int64_t want_blocks = 2048;
+        int64_t splits = (want_blocks + d.n_out - 1) / d.n_out;
+        int64_t min_seg = 4096;                                   // at least 16 KiB per block
+        if (splits * min_seg > d.rlen) splits = (d.rlen + min_seg - 1) / min_seg;
+        if (splits < 1) splits = 1;
+        int64_t seg = ((d.rlen + splits - 1) / splits + 3) & ~int64_t(3);
+        splits = (d.rlen + seg - 1) / seg;
+        if (d.n_out > 65535) {   // grid.y limit: fall back to a wave per row
+            hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, in, out, d);
+            return LG_OK;
+        }
+        if (splits == 1) {
+            hipLaunchKernelGGL((red_rows_split<OP>), dim3(1, unsigned(d.n_out)), dim3(256), 0, s, in, out, d, seg);
+            return LG_OK;
+        }
+        float* partial = nullptr;
+        int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
+        if (rc != LG_OK) return rc;
+        hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, partial, d, seg);
+        RedDesc d2{};
+        d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
+        d2.kshape[0] = d.n_out; d2.kstride[0] = splits; d2.rshape[0] = splits; d2.rstride[0] = 1;
+        hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, partial, out, d2);
+        return lg_free(partial);   // stream-ordered: the block is only reused by later launches
+    }
+
+    // general / column reduce
+    int64_t blocks_x = (d.n_out + 255) / 256;
+    int64_t splits = 1;
+    if (blocks_x < 1024 && d.rlen >= 64) {
+        splits = 1024 / blocks_x;
+        if (splits * 16 > d.rlen) splits = d.rlen / 16;           // at least 16 elements per thread
+        if (splits < 1) splits = 1;
+        if (splits > 65535) splits = 65535;
+    }
+    int64_t chunk = (d.rlen + splits - 1) / splits;
+    splits = (d.rlen + chunk - 1) / chunk;
+    if (blocks_x >= (int64_t(1) << 31)) { set_error("lg_reduce: output too large"); return LG_EINVAL; }
+    if (splits == 1) {
+        hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, in, out, d, chunk);
+        return LG_OK;
+    }
+    float* partial = nullptr;
+    int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
+    if (rc != LG_OK) return rc;
+    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, s, in, partial, d, chunk);
+    RedDesc d2{};
+    d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
+    d2.kshape[0] = d.n_out; d2.kstride[0] = 1; d2.rshape[0] = splits; d2.rstride[0] = d.n_out;
+    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, partial, out, d2, splits);
+    return lg_free(partial);
+}
+
+}  // namespace lg
+
+using namespace lg;
+
+extern "C" int lg_reduce(int op, int ndim, const int64_t* shape, const void* in, const int64_t* in_strides,
+                         uint32_t axis_mask, void* out) {
+    LG_REQUIRE_INIT();
+    LG_ARG(ndim >= 0 && ndim <= LG_MAX_DIMS, "lg_reduce: ndim %d out of range [0, %d]", ndim, LG_MAX_DIMS);
+    LG_ARG(in != nullptr && out != nullptr, "lg_reduce: NULL pointer");
+    LG_ARG(ndim == 0 || (shape != nullptr && in_strides != nullptr), "lg_reduce: NULL shape/strides");
+    LG_ARG(op == LG_RED_SUM || op == LG_RED_MAX || op == LG_RED_MIN, "lg_reduce: unknown op id %d", op);
+    LG_ARG((axis_mask >> ndim) == 0, "lg_reduce: axis_mask 0x%x names a dimension >= ndim %d", axis_mask, ndim);
+
+    RedDesc d{};
+    int nk = 0, nr = 0;
+    d.n_out = 1;
+    d.rlen = 1;
+    for (int k = 0; k < ndim; ++k) {
+        LG_ARG(shape[k] >= 0, "lg_reduce: negative extent");
+        if ((axis_mask >> k) & 1u) {
+            d.rshape[nr] = shape[k]; d.rstride[nr] = in_strides[k]; ++nr;
+            d.rlen *= shape[k];
+        } else {
+            d.kshape[nk] = shape[k]; d.kstride[nk] = in_strides[k]; ++nk;
+            d.n_out *= shape[k];
+        }
+    }
+    if (d.n_out == 0) return LG_OK;
+    if (d.rlen == 0) {
+        LG_ARG(op == LG_RED_SUM, "lg_reduce: zero-size reduction has no identity for max/min");
+        uint64_t zero = 0;
+        int64_t n = d.n_out, one = 1;
+        return lg_fill_strided(4, 1, &n, out, &one, zero);
+    }
+    d.nk = collapse(nk, d.kshape, d.kstride);
+    d.nr = collapse(nr, d.rshape, d.rstride);
+
+    int rc;
+    const float* src = static_cast<const float*>(in);
+    float* dst = static_cast<float*>(out);
+    switch (op) {
+        case LG_RED_SUM: rc = run_reduce<LG_RED_SUM>(src, dst, d); break;
+        case LG_RED_MAX: rc = run_reduce<LG_RED_MAX>(src, dst, d); break;
+        default:         rc = run_reduce<LG_RED_MIN>(src, dst, d); break;
+    }
+    if (rc != LG_OK) return rc;
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

@@ -1,0 +1,227 @@
+"""Data-parallel training: one process per GPU, ONE gradient all-reduce per step.
+
+The reference has no distributed code; this module is the MI355X-native
+addition for BASELINE config #4.  Design:
+  * every rank holds a full replica and draws its own batch;
+  * parameter gradients are VIEWS into one flat bucket (MLP: 407 050 fp32 = 1.63 MB), so the
+    exchange is a single in-place all-reduce with no pack/unpack kernels.  Over xGMI a message
+    of this size is latency-bound, hence exactly one collective per step, enqueued on the
+    compute stream between backward() and optim.step() with no host synchronisation;
+  * `mse.backward` carries no 1/N (loss.py:12), so the all-reduce SUM equals the gradient of the
+    concatenated batch; the mean (x 1/world) is folded into the optimizer (`grad_scale`).
+
+Two communicators implement the same interface:
+  RcclCommunicator  HipTensor buckets, RCCL through liblghip_comm.so (include/lghip_comm.h)
+  GlooCommunicator  CpuTensor buckets, torch.distributed/gloo - lets the bucket / scaling /
+                    determinism logic be tested with world_size 2 on a CPU-only machine
+"""
+import ctypes
+import os
+import time
+import numpy as np
+
+from .autograd import CpuTensor, HipTensor, Gradients
+
+
+class Communicator(object):
+    rank, world_size = 0, 1
+
+    def allreduce_sum_(self, flat):
+        raise NotImplementedError()
+
+    def allreduce_max_(self, flat):
+        raise NotImplementedError()
+
+    def broadcast_(self, flat, root=0):
+        raise NotImplementedError()
+
+    def barrier(self):
+        raise NotImplementedError()
+
+    def close(self):
+        pass
+
+
+class SingleProcess(Communicator):
+    """world_size 1: every collective is the identity"""
+
+    def allreduce_sum_(self, flat):
+        return flat
+
+    allreduce_max_ = allreduce_sum_
+
+    def broadcast_(self, flat, root=0):
+        return flat
+
+    def barrier(self):
+        pass
+
+
+class GlooCommunicator(Communicator):
+    """CPU ranks over torch.distributed (gloo); the process group must already be initialised"""
+
+    def __init__(self):
+        import torch.distributed as dist
+        assert dist.is_initialized(), "call torch.distributed.init_process_group('gloo', ...) first"
+        self._dist = dist
+        self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+
+    def _tensor(self, flat):
+        import torch
+        assert isinstance(flat, CpuTensor) and flat.data.flags["C_CONTIGUOUS"]
+        return torch.from_numpy(flat.data)     # shares memory: the reduction lands in the bucket
+
+    def allreduce_sum_(self, flat):
+        self._dist.all_reduce(self._tensor(flat), op=self._dist.ReduceOp.SUM)
+        return flat
+
+    def allreduce_max_(self, flat):
+        self._dist.all_reduce(self._tensor(flat), op=self._dist.ReduceOp.MAX)
+        return flat
+
+    def broadcast_(self, flat, root=0):
+        self._dist.broadcast(self._tensor(flat), src=root)
+        return flat
+
+    def barrier(self):
+        self._dist.barrier()
+
+
+def _exchange_unique_id(rank, make_id, path, timeout=300.0):
+    """rank 0 writes the 128-byte RCCL id to `path` atomically, the others poll for it (single node)"""
+    if rank == 0:
+        blob = make_id()
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)
+        return blob
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if len(blob) == 128:
+                return blob
+        except FileNotFoundError:
+            pass
+        time.sleep(0.01)
+    raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout))
+
+
+class RcclCommunicator(Communicator):
+    """GPU ranks over RCCL/xGMI; collectives run on liblghip's compute stream"""
+
+    def __init__(self, rank=None, world_size=None, id_path=None):
+        from .autograd.hip import lib as L
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+        self._L = L
+        self._lib = L.comm_lib()
+        if id_path is None:
+            tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"))
+            id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lightgrad_rccl_%s.id" % tag)
+        self._id_path = id_path
+
+        def make_id():
+            buf = ctypes.create_string_buffer(128)
+            L.comm_check(self._lib.lg_comm_get_unique_id(buf))
+            return buf.raw
+        blob = _exchange_unique_id(self.rank, make_id, id_path)
+        L.comm_check(self._lib.lg_comm_init(self.rank, self.world_size, ctypes.create_string_buffer(blob, 128)))
+        self.barrier()
+        if self.rank == 0:
+            try:
+                os.remove(id_path)
+            except OSError:
+                pass
+
+    def _check_flat(self, flat):
+        assert isinstance(flat, HipTensor) and flat.is_contiguous() and flat.dtype == np.float32
+        return flat
+
+    def allreduce_sum_(self, flat):
+        self._check_flat(flat)
+        self._L.comm_check(self._lib.lg_comm_allreduce_f32(flat.ptr, flat.numel(), 0))
+        return flat
+
+    def allreduce_max_(self, flat):
+        self._check_flat(flat)
+        self._L.comm_check(self._lib.lg_comm_allreduce_f32(flat.ptr, flat.numel(), 1))
+        return flat
+
+    def broadcast_(self, flat, root=0):
+        self._check_flat(flat)
+        self._L.comm_check(self._lib.lg_comm_broadcast_f32(flat.ptr, flat.numel(), root))
+        return flat
+
+    def barrier(self):
+        token = HipTensor.zeros((1,), requires_grad=False)
+        self.allreduce_sum_(token)
+        self._L.check(self._L.lib().lg_sync())
+
+    def close(self):
+        self._L.comm_check(self._lib.lg_comm_destroy())
+
+
+def _flat_and_views(cls, shapes):
+    """one dense fp32 bucket of class `cls` and a view of it per shape (no copies)"""
+    sizes = [int(np.prod(s, dtype=np.int64)) if len(s) else 1 for s in shapes]
+    total = sum(sizes)
+    views, off = [], 0
+    if cls is HipTensor or issubclass(cls, HipTensor):
+        flat = HipTensor.zeros((total,), requires_grad=False)
+        for s, n in zip(shapes, sizes):
+            views.append(HipTensor(flat.data, s, None, flat.offset + off, flat.dtype, requires_grad=False))
+            off += n
+    elif issubclass(cls, CpuTensor):
+        flat = cls(np.zeros((total,), dtype=np.float32), requires_grad=False)
+        for s, n in zip(shapes, sizes):
+            views.append(cls(flat.data[off:off + n].reshape(s), requires_grad=False))
+            off += n
+    else:
+        raise TypeError("no flat-bucket support for %s" % cls.__name__)
+    return flat, views
+
+
+class DataParallel(object):
+    """Wraps a model's parameters for synchronous data-parallel SGD.
+
+        dp = DataParallel(model.parameters(), comm)      # grads become views into one bucket
+        optim = AdaBelief(model.parameters(), lr=1e-3, grad_scale=dp.grad_scale)
+        ...
+        optim.zero_grad(); loss.backward(); dp.sync_gradients(); optim.step()
+    """
+
+    def __init__(self, parameters, comm: Communicator, broadcast_parameters: bool = True):
+        self.parameters = tuple(parameters)
+        self.comm = comm
+        assert len(self.parameters) > 0
+        cls = self.parameters[0].__class__
+        self.bucket, views = _flat_and_views(cls, [p.shape for p in self.parameters])
+        for p, g in zip(self.parameters, views):
+            assert p.requires_grad and p.dtype == np.float32
+            p._grad = g           # zero_grad -> fill(0) and add_grad -> += both act in place on the view
+        self.grad_scale = 1.0 / comm.world_size
+        if broadcast_parameters and comm.world_size > 1:
+            self.broadcast_parameters()
+
+    def broadcast_parameters(self, root: int = 0):
+        """make every replica start from rank `root`'s weights (one flat broadcast)"""
+        cls = self.parameters[0].__class__
+        flat, views = _flat_and_views(cls, [p.shape for p in self.parameters])
+        with Gradients.no_grad():      # setitem must not become the parameters' tape context
+            for p, v in zip(self.parameters, views):
+                v[...] = p
+            self.comm.broadcast_(flat, root)
+            for p, v in zip(self.parameters, views):
+                p[...] = v
+
+    def sync_gradients(self):
+        """sum the gradient bucket over all ranks, in place, asynchronously"""
+        if self.comm.world_size > 1:
+            self.comm.allreduce_sum_(self.bucket)
+
+    def parameter_digest(self) -> float:
+        """sum of |w| over all parameters: equal on every rank iff the replicas are in sync"""
+        return float(sum(np.abs(p.numpy().astype(np.float64)).sum() for p in self.parameters))

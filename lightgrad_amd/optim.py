@@ -1,0 +1,97 @@
+"""Optimizers written as tensor expressions, backend-agnostic.
+
+Restates the reference's `lightgrad/optim.py`: `step` adds `compute_delta(grad, i)`
+to each parameter in place under no_grad (optim.py:10-13); SGD with momentum
+(:15-25); Adam (:27-41) and AdaBelief (:43-52).  Note the reference quirk that
+is kept on purpose: `self.t` advances once per *parameter*, not once per step
+(optim.py:36, :48), so bias correction differs between parameters of one step.
+
+A backend may provide a fused update through the optional tensor method
+`_fused_adam_step(...)` (HipTensor does: one kernel per parameter instead of
+~14 elementwise launches - SURVEY.md §8f row 1); the expression form below is
+the definition and the fallback for every other backend.
+"""
+from .autograd import Gradients, AbstractTensor
+
+
+class Optimizer(object):
+
+    def __init__(self, parameters) -> None:
+        self.parameters = tuple(parameters)
+        assert all(isinstance(p, AbstractTensor) for p in self.parameters)
+
+    def zero_grad(self) -> None:
+        for p in self.parameters:
+            p.zero_grad()
+
+    @Gradients.no_grad()
+    def step(self) -> None:
+        for i, p in enumerate(self.parameters):
+            p += self.compute_delta(p.grad, i)
+
+    def compute_delta(self, grad: AbstractTensor, idx: int) -> AbstractTensor:
+        raise NotImplementedError()
+
+
+class SGD(Optimizer):
+    """ Stochastic Gradient Descent """
+
+    def __init__(self, parameters, lr: float, momentum: float = 0.0):
+        Optimizer.__init__(self, parameters)
+        self.prev_deltas = [0] * len(self.parameters)
+        self.lr, self.momentum = lr, momentum
+
+    def compute_delta(self, grad, i):
+        self.prev_deltas[i] = -self.lr * grad + self.momentum * self.prev_deltas[i]
+        return self.prev_deltas[i]
+
+
+class Adam(Optimizer):
+    """ ADAptive Moment estimation """
+
+    belief = False
+
+    def __init__(self, parameters, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                 fused: bool = False, grad_scale: float = 1.0):
+        Optimizer.__init__(self, parameters)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = [0] * len(self.parameters)
+        self.v = [0] * len(self.parameters)
+        # fused: use the backend's one-kernel update when the tensor class offers `_fused_adam_step`
+        # grad_scale: factor applied to every gradient first (1/world_size in data-parallel training)
+        self.fused, self.grad_scale = fused, grad_scale
+
+    @Gradients.no_grad()
+    def step(self) -> None:
+        for i, p in enumerate(self.parameters):
+            kernel = getattr(p, "_fused_adam_step", None) if self.fused else None
+            if kernel is None:
+                g = p.grad if self.grad_scale == 1.0 else p.grad * self.grad_scale
+                p += self.compute_delta(g, i)
+                continue
+            self.t += 1
+            if not isinstance(self.m[i], AbstractTensor):
+                self.m[i] = p.__class__.zeros(p.shape, requires_grad=False)
+                self.v[i] = p.__class__.zeros(p.shape, requires_grad=False)
+            kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
+                   (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
+
+    def second_moment_input(self, grad, m):
+        return grad
+
+    def compute_delta(self, grad, i):
+        self.t += 1
+        self.m[i] = self.b1 * self.m[i] + (1 - self.b1) * grad
+        self.v[i] = self.b2 * self.v[i] + (1 - self.b2) * self.second_moment_input(grad, self.m[i])**2
+        m, v = self.m[i] / (1 - self.b1**self.t), self.v[i] / (1 - self.b2**self.t)
+        return -self.lr * m / (v**0.5 + self.eps)
+
+
+class AdaBelief(Adam):
+    """ Adapting Stepsizes by the Belief in Observed Gradients (arXiv:2010.07468):
+    the second moment tracks (grad - m)^2 instead of grad^2 """
+    belief = True
+
+    def second_moment_input(self, grad, m):
+        return grad - m

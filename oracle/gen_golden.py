@@ -1,0 +1,156 @@
+"""Generate tests/golden/*.npz from the REAL reference (ndoll1998/lightgrad @ /root/reference).
+
+TEST INFRASTRUCTURE - runs only in the build container (the reference never travels to the
+GPU box).  It imports the reference's CPU backend with the pyopencl stub described in
+SURVEY.md §8c (the reference's own `import pyopencl` fails with an ordinary ModuleNotFoundError
+here), evaluates the hot-path ops forward + backward on seeded inputs and stores inputs and
+outputs as small fixtures.  The fixtures pin both the numpy oracle (oracle/np_oracle.py) and
+the product backends (CpuTensor on CPU, HipTensor on the GPU).
+
+    python oracle/gen_golden.py            # rewrites tests/golden/
+
+Only DATA is written (inputs / expected outputs); no reference source text is copied.
+"""
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cases import f32  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    cl = mock.MagicMock(name="pyopencl")
+    cl.__path__ = []
+
+    def _none():
+        raise RuntimeError("no opencl")      # swallowed by the reference's bare except (opencl/device.py:16-22)
+    cl.get_platforms = _none
+    tools = mock.MagicMock(name="pyopencl.tools")
+    cl.tools = tools
+    sys.modules["pyopencl"], sys.modules["pyopencl.tools"] = cl, tools
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import lightgrad as light               # noqa: E402
+    return light
+
+
+def main():
+    light = import_reference()
+    T = light.CpuTensor
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.RandomState(20261003)
+
+    # ---------------------------------------------------------------- elementwise / unary
+    cases = {}
+
+    def run(name, fn, inputs, upstream=True):
+        """forward + backward of fn(*tensors) with upstream gradient w (via `(y * w).backward(allow_fill)`)"""
+        ts = [T.from_numpy(a.copy()) for a in inputs]
+        y = fn(*ts)
+        rec = {"in%d" % i: a for i, a in enumerate(inputs)}
+        rec["out"] = np.array(y.numpy())
+        if upstream:
+            w = f32(rng, -1, 1, y.shape)
+            rec["w"] = w
+            (y * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+            for i, t in enumerate(ts):
+                if t.grad is not None:
+                    rec["grad%d" % i] = np.array(t.grad.numpy())
+        for k, v in rec.items():
+            cases["%s/%s" % (name, k)] = v
+
+    from cases import op_cases
+    for case in op_cases(T, rng):
+        run(*case)
+
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **cases)
+
+    # ---------------------------------------------------------------- examples/gradient_descent.py trajectory
+    # the script body, seeded as in SURVEY.md §8a row a13 (np.random.seed(1234) right before it)
+    np.random.seed(1234)
+    A = light.uniform(-1, 1, shape=(10, 10))
+    Bt = light.uniform(-1, 1, shape=(10, 10))
+    Ct = light.uniform(-1, 1, shape=(10, 10))
+    init = [A.numpy().copy(), Bt.numpy().copy(), Ct.numpy().copy()]
+    ys = []
+    for _ in range(100):
+        y = (A.tanh() + Bt.sigmoid()) @ (Ct.relu() - A.sigmoid())
+        y.backward(allow_fill=True)
+        with light.no_grad():
+            A -= 0.1 * A.grad
+            Bt -= 0.1 * Bt.grad
+            Ct -= 0.1 * Ct.grad
+        y.zero_grad(traverse_graph=True)
+        ys.append(y.sum().item())
+    np.savez_compressed(os.path.join(OUT, "gradient_descent.npz"), ys=np.asarray(ys, dtype=np.float64),
+                        a0=init[0], b0=init[1], c0=init[2],
+                        a_final=A.numpy(), b_final=Bt.numpy(), c_final=Ct.numpy())
+
+    # ---------------------------------------------------------------- MLP training trajectories
+    import lightgrad.nn as nn
+
+    def mlp_traj(d_in, d_hid, d_out, batch, steps, opt_name, seed, store_inputs):
+        class MLP(nn.Module):
+            def __init__(self):
+                nn.Module.__init__(self)
+                self.l1 = nn.Linear(d_in, d_hid)
+                self.l2 = nn.Linear(d_hid, d_out)
+
+            def forward(self, xx):
+                return self.l2(self.l1(xx.reshape(-1, d_in)).relu())
+        np.random.seed(seed)
+        model = MLP()
+        w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
+        xb = np.random.uniform(0, 1, size=(batch, d_in)).astype(np.float32)
+        labels = np.random.randint(0, d_out, size=batch)
+        onehot = np.zeros((batch, d_out), dtype=np.float32)
+        onehot[np.arange(batch), labels] = 1
+        if opt_name == "adabelief":
+            opt = light.optim.AdaBelief(model.parameters(), lr=1e-3)
+        elif opt_name == "adam":
+            opt = light.optim.Adam(model.parameters(), lr=1e-3)
+        else:
+            opt = light.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
+        losses, grads0 = [], None
+        for s in range(steps):
+            yy = model(T.from_numpy(xb))
+            l = light.loss.mse(yy, T.from_numpy(onehot))
+            opt.zero_grad()
+            l.backward()
+            if s == 0:
+                grads0 = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+            opt.step()
+            losses.append(l.item())
+        rec = {"losses": np.asarray(losses, dtype=np.float64), "labels": labels.astype(np.int64),
+               "config": np.asarray([d_in, d_hid, d_out, batch, steps, seed], dtype=np.int64)}
+        wf = {n: p.numpy() for n, p in model.named_parameters()}
+        if store_inputs:
+            rec["x"] = xb
+            for n in w0:
+                rec["w0/" + n] = w0[n]
+                rec["wf/" + n] = wf[n]
+                rec["g0/" + n] = grads0[n]
+        else:
+            # full-size config: inputs are regenerated from the seed; keep digests + a strided sample of outputs
+            for n in w0:
+                rec["w0sum/" + n] = np.asarray([w0[n].astype(np.float64).sum(), np.abs(w0[n]).astype(np.float64).sum()])
+                rec["wfsum/" + n] = np.asarray([wf[n].astype(np.float64).sum(), np.abs(wf[n]).astype(np.float64).sum()])
+                rec["wfsample/" + n] = wf[n].reshape(-1)[::max(1, wf[n].size // 64)][:64].copy()
+                rec["g0sample/" + n] = grads0[n].reshape(-1)[::max(1, grads0[n].size // 64)][:64].copy()
+        return rec
+
+    np.savez_compressed(os.path.join(OUT, "mlp_small_adabelief.npz"), **mlp_traj(20, 16, 10, 8, 12, "adabelief", 7, True))
+    np.savez_compressed(os.path.join(OUT, "mlp_small_adam.npz"), **mlp_traj(20, 16, 10, 8, 12, "adam", 8, True))
+    np.savez_compressed(os.path.join(OUT, "mlp_small_sgd.npz"), **mlp_traj(20, 16, 10, 8, 12, "sgd", 9, True))
+    np.savez_compressed(os.path.join(OUT, "mlp_full_adabelief.npz"), **mlp_traj(784, 512, 10, 1024, 5, "adabelief", 0, False))
+    print("fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

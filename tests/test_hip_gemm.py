@@ -1,0 +1,142 @@
+"""SGEMM parity: every operand layout (row-/column-major views), ragged and tiny shapes, batches,
+accumulate mode through the raw C ABI, and BASELINE's 4096^2 forward+backward through size-independent
+properties.  Error metric: relative Frobenius error against float64 numpy <= 1e-5."""
+import ctypes
+import numpy as np
+import pytest
+import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, ref64):
+    return np.linalg.norm(got.astype(np.float64) - ref64) / max(np.linalg.norm(ref64), 1e-30)
+
+
+SHAPES = [(1, 1, 1), (1, 7, 1), (3, 5, 2), (32, 32, 32), (33, 31, 35), (64, 64, 64), (65, 129, 67), (128, 128, 128),
+          (127, 255, 96), (256, 100, 256), (1024, 784, 512), (1024, 512, 10), (1024, 10, 512), (784, 1024, 512), (10, 1024, 512),
+          (200, 36, 300), (130, 8, 70), (512, 4, 512), (257, 130, 513)]
+
+
+@pytest.mark.parametrize("mkn", SHAPES)
+def test_all_layouts(hip, mkn):
+    M, K, N = mkn
+    rng = np.random.RandomState(M * 7 + K * 3 + N)
+    a, b = rng.uniform(-1, 1, (M, K)).astype(np.float32), rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    ta_t = hip.from_numpy(np.ascontiguousarray(a.T)).transpose(1, 0)       # column-major view of the same values
+    tb_t = hip.from_numpy(np.ascontiguousarray(b.T)).transpose(1, 0)
+    for x, y, tag in [(ta, tb, "NN"), (ta, tb_t, "NT"), (ta_t, tb, "TN"), (ta_t, tb_t, "TT")]:
+        out = (x @ y).numpy()
+        assert out.shape == (M, N)
+        assert rel_err(out, ref) <= 1e-5, (tag, mkn, rel_err(out, ref))
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5 * K ** 0.5, err_msg=tag)
+
+
+def test_identity_is_exact(hip):
+    """A @ I == A bit for bit, in every layout: catches a swapped C/D row<->col map (asymmetric A)"""
+    rng = np.random.RandomState(5)
+    a = rng.uniform(-1, 1, (192, 160)).astype(np.float32)
+    eye = np.eye(160, dtype=np.float32)
+    ta, te = hip.from_numpy(a), hip.from_numpy(eye)
+    np.testing.assert_array_equal((ta @ te).numpy(), a)
+    np.testing.assert_array_equal((ta @ te.transpose(1, 0)).numpy(), a)
+    np.testing.assert_array_equal((hip.from_numpy(np.eye(192, dtype=np.float32)) @ ta).numpy(), a)
+    at = hip.from_numpy(np.ascontiguousarray(a.T)).transpose(1, 0)
+    np.testing.assert_array_equal((at @ te).numpy(), a)
+
+
+def test_backward_layouts_match_oracle(hip):
+    rng = np.random.RandomState(6)
+    for (M, K, N) in [(10, 15, 10), (64, 48, 20), (130, 70, 200)]:
+        a, b = rng.uniform(-1, 1, (M, K)).astype(np.float32), rng.uniform(-1, 1, (K, N)).astype(np.float32)
+        w = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        ga, gb = O.dot_backward(w.astype(np.float64), a.astype(np.float64), b.astype(np.float64))
+        for ta_view in (False, True):
+            for tb_view in (False, True):
+                ta = hip.from_numpy(np.ascontiguousarray(a.T)).transpose(1, 0) if ta_view else hip.from_numpy(a)
+                tb = hip.from_numpy(np.ascontiguousarray(b.T)).transpose(1, 0) if tb_view else hip.from_numpy(b)
+                y = ta @ tb
+                (y * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+                assert rel_err(ta.grad.numpy(), ga) <= 1e-5 and rel_err(tb.grad.numpy(), gb) <= 1e-5
+
+
+def test_linear_weight_gradient_is_dense(hip):
+    """x @ W.T(1,0): dW comes back through transpose.backward as a dense (out,in) tensor - no strided accumulate"""
+    rng = np.random.RandomState(7)
+    x, w = rng.uniform(-1, 1, (32, 48)).astype(np.float32), rng.uniform(-1, 1, (20, 48)).astype(np.float32)
+    tx, tw = hip.from_numpy(x), hip.from_numpy(w)
+    y = tx @ tw.T(1, 0)
+    y.backward(allow_fill=True)
+    assert tw.grad.shape == (20, 48) and tw.grad.is_contiguous()
+    np.testing.assert_allclose(tw.grad.numpy(), np.ones((32, 20)).T @ x.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+def test_batched(hip):
+    rng = np.random.RandomState(8)
+    a = rng.uniform(-1, 1, (3, 4, 33, 20)).astype(np.float32)
+    b = rng.uniform(-1, 1, (3, 4, 20, 17)).astype(np.float32)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    assert rel_err((ta @ tb).numpy(), a.astype(np.float64) @ b) <= 1e-5
+    b2 = rng.uniform(-1, 1, (20, 17)).astype(np.float32)
+    assert rel_err((ta @ hip.from_numpy(b2)).numpy(), a.astype(np.float64) @ b2) <= 1e-5          # one tall GEMM
+    b3 = rng.uniform(-1, 1, (4, 20, 17)).astype(np.float32)
+    assert rel_err((ta @ hip.from_numpy(b3)).numpy(), a.astype(np.float64) @ b3) <= 1e-5          # broadcast batch
+    # attention-style head split: (b, s, h, d) -> transpose(0, 2, 1, 3): batch dims do not collapse
+    q = rng.uniform(-1, 1, (2, 16, 4, 8)).astype(np.float32)
+    k = rng.uniform(-1, 1, (2, 16, 4, 8)).astype(np.float32)
+    tq, tk = hip.from_numpy(q).transpose(0, 2, 1, 3), hip.from_numpy(k).transpose(0, 2, 3, 1)
+    ref = q.transpose(0, 2, 1, 3).astype(np.float64) @ k.transpose(0, 2, 3, 1)
+    assert rel_err((tq @ tk).numpy(), ref) <= 1e-5
+    # vectors
+    v = rng.uniform(-1, 1, (20,)).astype(np.float32)
+    np.testing.assert_allclose((hip.from_numpy(a[0, 0]) @ hip.from_numpy(v)).numpy(), a[0, 0].astype(np.float64) @ v, rtol=1e-5, atol=1e-5)
+
+
+def test_c_abi_accumulate_and_errors(hip):
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(9)
+    M, K, N = 70, 40, 50
+    a, b, c = (rng.uniform(-1, 1, s).astype(np.float32) for s in [(M, K), (K, N), (M, N)])
+    ta, tb, tc = hip.from_numpy(a), hip.from_numpy(b), hip.from_numpy(c)
+    assert lib.lg_gemm_f32(0, 0, M, N, K, ta.ptr, K, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 1) == 0
+    np.testing.assert_allclose(tc.numpy(), c + a.astype(np.float64) @ b, rtol=1e-5, atol=1e-5)
+    assert lib.lg_gemm_f32(0, 0, M, N, K, ta.ptr, K - 1, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 0) == -1       # lda < K
+    assert b"leading dimension" in lib.lg_last_error()
+    assert lib.lg_gemm_f32(0, 0, M, N, K, None, K, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 0) == -1
+    assert lib.lg_ew(12345, 1, L.i64((4,)), tc.ptr, L.i64((1,)), None, None, ta.ptr, L.i64((1,)), None, None, None, None,
+                     None, None, 0.0) == -1
+    assert b"unknown op" in lib.lg_last_error()
+    assert lib.lg_free(ctypes.c_void_p(12345)) == -1
+
+
+def test_4096_forward_backward_properties(hip):
+    """BASELINE config #2 at full size: y = A @ B; y.backward(allow_fill=True)."""
+    n = 4096
+    np.random.seed(0)
+    a = np.random.uniform(-1, 1, (n, n)).astype(np.float32)
+    b = np.random.uniform(-1, 1, (n, n)).astype(np.float32)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    y = ta @ tb
+    y.backward(allow_fill=True)
+    yn, ga, gb = y.numpy(), ta.grad.numpy(), tb.grad.numpy()
+    # (1) sampled blocks against float64 numpy
+    rng = np.random.RandomState(1)
+    for _ in range(6):
+        i, j = rng.randint(0, n - 128, 2)
+        ref = a[i:i + 128].astype(np.float64) @ b[:, j:j + 128].astype(np.float64)
+        assert rel_err(yn[i:i + 128, j:j + 128], ref) <= 1e-5
+    # (2) checksum of checksums: (A @ B) @ 1 == A @ (B @ 1), 1^T (A @ B) == (1^T A) @ B
+    ones = np.ones(n)
+    np.testing.assert_allclose(yn.astype(np.float64) @ ones, a.astype(np.float64) @ (b.astype(np.float64) @ ones), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(ones @ yn.astype(np.float64), (ones @ a.astype(np.float64)) @ b.astype(np.float64), rtol=1e-4, atol=2e-2)
+    # (3) gradients with an all-ones upstream: dA[i, k] = sum_j B[k, j] (every row equal), dB[k, j] = sum_i A[i, k]
+    ra, rb = b.astype(np.float64).sum(axis=1), a.astype(np.float64).sum(axis=0)
+    np.testing.assert_allclose(ga, np.broadcast_to(ra, (n, n)), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(gb, np.broadcast_to(rb[:, None], (n, n)), rtol=1e-4, atol=2e-3)
+    assert rel_err(ga, np.broadcast_to(ra, (n, n))) <= 1e-5 and rel_err(gb, np.broadcast_to(rb[:, None], (n, n))) <= 1e-5
+    # (4) linearity: (2A) @ B == 2 (A @ B) exactly (power-of-two scaling commutes with rounding)
+    y2 = ((ta * 2.0) @ tb).numpy()
+    np.testing.assert_array_equal(y2, 2 * yn)

@@ -1,0 +1,81 @@
+"""The MNIST-MLP training step on the HIP path against trajectories recorded from the reference
+(tests/golden/mlp_*.npz) and against the numpy oracle; fused optimizer against the tape form."""
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from lightgrad_amd import CpuTensor
+from conftest import load_golden
+import np_oracle as O
+from test_cpu_backend import MLP, train
+
+pytestmark = pytest.mark.gpu
+
+
+def make_opt(name, params, **kw):
+    return {"adabelief": lambda: light.optim.AdaBelief(params, lr=1e-3, **kw), "adam": lambda: light.optim.Adam(params, lr=1e-3, **kw),
+            "sgd": lambda: light.optim.SGD(params, lr=1e-4, momentum=0.9)}[name]()
+
+
+@pytest.mark.parametrize("opt_name", ["adabelief", "adam", "sgd"])
+def test_small_trajectory_vs_reference(hip, opt_name):
+    g = load_golden("mlp_small_%s.npz" % opt_name)
+    d_in, d_hid, d_out, batch, steps, seed = (int(v) for v in g["config"])
+    model = MLP(d_in, d_hid, d_out)
+    model.load_parameters({n: g["w0/" + n] for n in O.PARAM_ORDER})
+    model.map_parameters(lambda p: p.hip())
+    onehot = np.zeros((batch, d_out), np.float32)
+    onehot[np.arange(batch), g["labels"]] = 1
+    losses, g0 = train(model, hip.from_numpy, g["x"], onehot, steps, make_opt(opt_name, model.parameters()))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        assert isinstance(p, hip)
+        np.testing.assert_allclose(g0[n], g["g0/" + n], rtol=1e-5, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+
+
+def test_full_size_trajectory_vs_reference(hip):
+    """BASELINE config #3: 784 -> 512 -> 10, batch 1024, mse, AdaBelief(lr=1e-3), 5 steps"""
+    g = load_golden("mlp_full_adabelief.npz")
+    d_in, d_hid, d_out, batch, steps, seed = (int(v) for v in g["config"])
+    w0, x, onehot, labels = O.synthetic_mlp_problem(seed, d_in, d_hid, d_out, batch)
+    model = MLP(d_in, d_hid, d_out)
+    model.load_parameters(w0)
+    model.map_parameters(lambda p: p.hip())
+    losses, g0 = train(model, hip.from_numpy, x, onehot, steps, make_opt("adabelief", model.parameters()))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    sample = lambda a: a.reshape(-1)[::max(1, a.size // 64)][:64]   # noqa: E731
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(sample(g0[n]), g["g0sample/" + n], rtol=2e-4, atol=1e-4, err_msg=n)
+        np.testing.assert_allclose(sample(p.numpy()), g["wfsample/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+        w = p.numpy().astype(np.float64)
+        np.testing.assert_allclose([w.sum(), np.abs(w).sum()], g["wfsum/" + n], rtol=1e-4, atol=1e-3)
+
+
+def test_step_gradients_vs_oracle_on_fresh_seed(hip):
+    w0, x, onehot, _ = O.synthetic_mlp_problem(123, 100, 64, 10, 256)
+    loss_o, grads_o, dx_o = O.mlp_loss_and_grads(w0, x, onehot)
+    model = MLP(100, 64, 10)
+    model.load_parameters(w0)
+    model.map_parameters(lambda p: p.hip())
+    tx = hip.from_numpy(x)
+    l = light.loss.mse(model(tx), hip.from_numpy(onehot))
+    l.backward()
+    np.testing.assert_allclose(l.item(), loss_o, rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), grads_o[n], rtol=1e-5, atol=1e-5, err_msg=n)
+    np.testing.assert_allclose(tx.grad.numpy(), dx_o, rtol=1e-5, atol=1e-6)     # dX is computed for the input layer too
+
+
+@pytest.mark.parametrize("opt_name", ["adabelief", "adam"])
+def test_fused_optimizer_equals_tape_form(hip, opt_name):
+    g = load_golden("mlp_small_%s.npz" % opt_name)
+    d_in, d_hid, d_out, batch, steps, seed = (int(v) for v in g["config"])
+    onehot = np.zeros((batch, d_out), np.float32)
+    onehot[np.arange(batch), g["labels"]] = 1
+    model = MLP(d_in, d_hid, d_out)
+    model.load_parameters({n: g["w0/" + n] for n in O.PARAM_ORDER})
+    model.map_parameters(lambda p: p.hip())
+    losses, _ = train(model, hip.from_numpy, g["x"], onehot, steps, make_opt(opt_name, model.parameters(), fused=True))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)

@@ -6,6 +6,7 @@ opencl/ops.py = view semantics); citations per class.
 
 Nothing here synchronises with the device and nothing falls back to numpy.
 """
+import builtins as _py      # this module defines ops named max / min / sum / pow
 import ctypes
 import numpy as np
 from ..func import Function
@@ -28,7 +29,7 @@ def _require_f32(*tensors):
 
 
 def _broadcast_shapes(*shapes):
-    nd = max(len(s) for s in shapes)
+    nd = _py.max(len(s) for s in shapes)
     out = [1] * nd
     for s in shapes:
         for i, d in enumerate(s):
@@ -252,9 +253,9 @@ class _Mat(object):
 
     def __init__(self, t, rows, cols, sr, sc):
         if cols == 1 or sc == 1:
-            self.colmajor, self.ld, self.t = False, max(sr, cols) if rows > 1 else cols, t
+            self.colmajor, self.ld, self.t = False, _py.max(sr, cols) if rows > 1 else cols, t
         elif rows == 1 or sr == 1:
-            self.colmajor, self.ld, self.t = True, max(sc, rows) if cols > 1 else rows, t
+            self.colmajor, self.ld, self.t = True, _py.max(sc, rows) if cols > 1 else rows, t
         else:
             raise ValueError("not a GEMM operand layout")
         self.rows, self.cols = rows, cols
@@ -354,9 +355,9 @@ def _gemm(a, b, out_colmajor=False):
             # leading dims, batch the innermost one
             inner = batch_shape[-1]
             for idx in np.ndindex(*batch_shape[:-1]):
-                oa = sum(i * s for i, s in zip(idx, sa[:-1])) * 4
-                ob = sum(i * s for i, s in zip(idx, sb[:-1])) * 4
-                oo = sum(i * s for i, s in zip(idx, so[:-1])) * 4
+                oa = _py.sum(i * s for i, s in zip(idx, sa[:-1])) * 4
+                ob = _py.sum(i * s for i, s in zip(idx, sb[:-1])) * 4
+                oo = _py.sum(i * s for i, s in zip(idx, so[:-1])) * 4
                 launch(a.ptr + oa, b.ptr + ob, out.ptr + oo, inner, sa[-1], sb[-1], M * N)
     if out_colmajor:
         nd = len(out_shape)
@@ -499,7 +500,7 @@ def _idx_view(a, idx):
     if any(isinstance(i, (list, np.ndarray, HipTensor, range)) for i in idx):
         raise NotImplementedError("HipTensor supports basic indexing only (ints, slices, Ellipsis, None); "
                                   "index on a CpuTensor and move the result with .hip()")
-    n_real = sum(1 for i in idx if i is not None and i is not Ellipsis)
+    n_real = _py.sum(1 for i in idx if i is not None and i is not Ellipsis)
     if Ellipsis in idx:
         k = idx.index(Ellipsis)
         idx = idx[:k] + (slice(None),) * (len(a._shape) - n_real) + idx[k + 1:]

@@ -147,7 +147,9 @@ class HipTensor(AbstractTensor):
 
     @staticmethod
     def from_numpy(a: np.ndarray, requires_grad: bool = True) -> "HipTensor":
-        a = np.ascontiguousarray(a)
+        a = np.asarray(a)
+        if not a.flags["C_CONTIGUOUS"]:
+            a = a.copy(order="C")          # (np.ascontiguousarray would turn a 0-d array into shape (1,))
         t = HipTensor.empty(a.shape, dtype=a.dtype, requires_grad=requires_grad)
         if a.nbytes > 0:
             _l.check(_l.lib().lg_memcpy_h2d(t.ptr, a.ctypes.data, a.nbytes))

@@ -145,6 +145,7 @@ int lg_device_info(lg_device_info_t* out) {
     snprintf(out->arch, sizeof(out->arch), "%s", prop.gcnArchName);
     // gcnArchName looks like "gfx950:sramecc+:xnack-": keep the target id only
     if (char* colon = strchr(out->arch, ':')) *colon = '\0';
+    if (out->name[0] == '\0') snprintf(out->name, sizeof(out->name), "AMD Instinct (%s)", out->arch);
     out->compute_units = prop.multiProcessorCount;
     out->clock_mhz = prop.clockRate / 1000;
     out->wavefront_size = prop.warpSize;

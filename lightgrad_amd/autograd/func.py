@@ -147,7 +147,7 @@ class WrapperFunction(Function, metaclass=_WrapperFunctionType):
             for node in Gradients._schedule(self._internal_ctx):
                 for t in node.parent_tensors:
                     if t.ctx is not None:
-                        t._grad = None
+                        t._grad, t._grad_shared = None, False
             Gradients.backward(self._internal_ctx, out_grad)
         finally:
             for p, c in fenced:

@@ -80,6 +80,8 @@ class HipDevice(object):
 
 class HipTensor(AbstractTensor):
 
+    _adopt_first_grad = True      # intermediates share their first gradient (see AbstractTensor)
+
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):
         assert isinstance(buffer, HipBuffer)
@@ -175,9 +177,27 @@ class HipTensor(AbstractTensor):
                                           self.ptr, _l.i64(self._strides)))
         return out
 
+    def _is_dense_permutation(self) -> bool:
+        """True if the elements occupy one gap-free run of memory in SOME dimension order (e.g. a transposed
+        view of a dense tensor)"""
+        dims = sorted(((st, s) for s, st in zip(self._shape, self._strides) if s != 1), reverse=True)
+        expect = 1
+        for st, s in reversed(dims):
+            if st != expect:
+                return False
+            expect *= s
+        return True
+
     def copy(self, requires_grad: bool = True) -> "HipTensor":
-        out = HipTensor.empty(self._shape, dtype=self._dtype, requires_grad=requires_grad)
+        """independent copy; a dense-but-permuted view keeps its memory layout (like numpy's order='K'), so
+        the copy is one flat device memcpy and a later transpose back is dense again"""
         nd = len(self._shape)
+        if nd > 1 and not self.is_contiguous() and self._is_dense_permutation():
+            out = HipTensor(HipBuffer(self.numel() * self._dtype.itemsize), self._shape, self._strides, 0, self._dtype,
+                            requires_grad=requires_grad)
+            _l.check(_l.lib().lg_memcpy_d2d(out.ptr, self.ptr, self.numel() * self._dtype.itemsize))
+            return out
+        out = HipTensor.empty(self._shape, dtype=self._dtype, requires_grad=requires_grad)
         _l.check(_l.lib().lg_copy_strided(self._dtype.itemsize, nd, _l.i64(self._shape), out.ptr, _l.i64(out._strides),
                                           self.ptr, _l.i64(self._strides)))
         return out

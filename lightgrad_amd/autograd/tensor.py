@@ -32,9 +32,16 @@ class _TensorType(type):
 
 class AbstractTensor(metaclass=_TensorType):
 
+    # A backend may set this to let NON-LEAF tensors adopt the first gradient they receive instead of
+    # copying it (the copy of tensor.py:116 is kept for leaves).  The adopted tensor is treated as
+    # read-only: a second contribution makes a fresh sum, zero_grad replaces instead of filling.
+    # Values are identical to the copying form; it only removes one device copy per tape node.
+    _adopt_first_grad = False
+
     def __init__(self, data, requires_grad: bool = True) -> None:
         self._data = data
         self._grad = None
+        self._grad_shared = False
         self._requires_grad = requires_grad
         self._ctx = None
 
@@ -127,6 +134,7 @@ class AbstractTensor(metaclass=_TensorType):
             return
         if self.shape == (1,) or len(self.shape) == 0 or allow_fill:
             self._grad = self.__class__.ones(self.shape, requires_grad=False)
+            self._grad_shared = False
         else:
             raise RuntimeError("Can only backpropagate from item tensors!")
         Gradients.backward(self._ctx, self._grad)
@@ -137,7 +145,12 @@ class AbstractTensor(metaclass=_TensorType):
         Gradients.disable()
         try:
             if self._grad is None:
-                self._grad = grad.copy(requires_grad=False)
+                if self._adopt_first_grad and self._ctx is not None:
+                    self._grad, self._grad_shared = grad, True
+                else:
+                    self._grad = grad.copy(requires_grad=False)
+            elif self._grad_shared:
+                self._grad, self._grad_shared = self._grad + grad, False
             else:
                 self._grad += grad
         finally:
@@ -145,8 +158,8 @@ class AbstractTensor(metaclass=_TensorType):
 
     def zero_grad(self, traverse_graph: bool = False) -> None:
         if self._requires_grad:
-            if self._grad is None:
-                self._grad = self.__class__.zeros(self.shape, requires_grad=False)
+            if self._grad is None or self._grad_shared:
+                self._grad, self._grad_shared = self.__class__.zeros(self.shape, requires_grad=False), False
             else:
                 self._grad.fill(0)
         if traverse_graph and (self._ctx is not None):

@@ -47,11 +47,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + pos;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB>
 __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(TM >= 1 && TN >= 1 && BK % 8 == 0, "tile config");
+    static_assert(TM >= 1 && TN >= 1 && BK % 16 == 0, "tile config");
     constexpr int A_PITCH = AKC ? BK + 4 : BM;          // floats per LDS row
     constexpr int B_PITCH = BKC ? BK + 4 : BN;
     constexpr int A_TILE = AKC ? BM * A_PITCH : BK * A_PITCH;
@@ -73,7 +73,14 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int per_batch = g.tiles_m * g.tiles_n;
     const int batch = id / per_batch;
     const int t = id - batch * per_batch;
-    const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+    // grouped order: consecutive ids walk GROUP_M tile rows before moving to the next tile column, so the
+    // ~64 workgroups resident on one XCD at a time cover a near-square patch of C and share both their
+    // A row-panels and their B column-panels in that XCD's 4 MiB L2
+    constexpr int GROUP_M = 8;
+    const int gspan = GROUP_M * g.tiles_n;
+    const int first_m = (t / gspan) * GROUP_M;
+    const int gsize = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
+    const int tm = first_m + (t % gspan) % gsize, tn = (t % gspan) / gsize;
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
     const float* __restrict__ A = g.A + int64_t(batch) * g.sA;
     const float* __restrict__ B = g.B + int64_t(batch) * g.sB;
@@ -82,7 +89,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     float ra[A_ELEMS], rb[B_ELEMS];   // staging registers
 
     auto load_tile = [&](int64_t k0) {
-        if constexpr (VEC) {
+        if constexpr (VA) {
 #pragma unroll
             for (int i = 0; i < A_ELEMS / 4; ++i) {
                 const int f = tid + i * NT;
@@ -98,6 +105,22 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 }
                 ra[4 * i] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ELEMS; ++i) {
+                const int e = tid + i * NT;
+                float v = 0.f;
+                if constexpr (AKC) {
+                    const int row = e / BK, kk = e % BK;
+                    if (m0 + row < g.M && k0 + kk < g.K) v = A[(m0 + row) * g.lda + k0 + kk];
+                } else {
+                    const int kk = e / BM, mm = e % BM;
+                    if (k0 + kk < g.K && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
+                }
+                ra[i] = v;
+            }
+        }
+        if constexpr (VB) {
 #pragma unroll
             for (int i = 0; i < B_ELEMS / 4; ++i) {
                 const int f = tid + i * NT;
@@ -114,19 +137,6 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < A_ELEMS; ++i) {
-                const int e = tid + i * NT;
-                float v = 0.f;
-                if constexpr (AKC) {
-                    const int row = e / BK, kk = e % BK;
-                    if (m0 + row < g.M && k0 + kk < g.K) v = A[(m0 + row) * g.lda + k0 + kk];
-                } else {
-                    const int kk = e / BM, mm = e % BM;
-                    if (k0 + kk < g.K && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
-                }
-                ra[i] = v;
-            }
 #pragma unroll
             for (int i = 0; i < B_ELEMS; ++i) {
                 const int e = tid + i * NT;
@@ -146,20 +156,13 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     auto store_tile = [&](int buf) {
         float* a = lds + buf * BUF;
         float* b = lds + buf * BUF + A_TILE;
-        if constexpr (VEC) {
+        if constexpr (VA) {
 #pragma unroll
             for (int i = 0; i < A_ELEMS / 4; ++i) {
                 const int f = tid + i * NT;
                 const float4 v = make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
                 if constexpr (AKC) *reinterpret_cast<float4*>(a + (f / (BK / 4)) * A_PITCH + (f % (BK / 4)) * 4) = v;
                 else               *reinterpret_cast<float4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = v;
-            }
-#pragma unroll
-            for (int i = 0; i < B_ELEMS / 4; ++i) {
-                const int f = tid + i * NT;
-                const float4 v = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
-                if constexpr (BKC) *reinterpret_cast<float4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = v;
-                else               *reinterpret_cast<float4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = v;
             }
         } else {
 #pragma unroll
@@ -168,6 +171,16 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 if constexpr (AKC) a[(e / BK) * A_PITCH + (e % BK)] = ra[i];
                 else               a[(e / BM) * A_PITCH + (e % BM)] = ra[i];
             }
+        }
+        if constexpr (VB) {
+#pragma unroll
+            for (int i = 0; i < B_ELEMS / 4; ++i) {
+                const int f = tid + i * NT;
+                const float4 v = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
+                if constexpr (BKC) *reinterpret_cast<float4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = v;
+                else               *reinterpret_cast<float4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = v;
+            }
+        } else {
 #pragma unroll
             for (int i = 0; i < B_ELEMS; ++i) {
                 const int e = tid + i * NT;
@@ -185,11 +198,11 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto compute_tile = [&](int buf) {
+    auto compute_tile = [&](int buf, int kb_begin, int kb_end) {
         const float* a = lds + buf * BUF + (AKC ? (wm * TM * 32 + r) * A_PITCH + 4 * h : (4 * h) * A_PITCH + wm * TM * 32 + r);
         const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * TN * 32 + r) * B_PITCH + 4 * h : (4 * h) * B_PITCH + wn * TN * 32 + r);
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 8) {
+        for (int kb = kb_begin; kb < kb_end; kb += 8) {
             float fa[TM][4], fb[TN][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -229,8 +242,9 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         const int cur = int(kt & 1);
         const bool more = kt + 1 < nkt;
         if (more) load_tile((kt + 1) * BK);      // in flight during the MFMAs below
-        compute_tile(cur);
-        if (more) store_tile(cur ^ 1);
+        compute_tile(cur, 0, BK / 2);
+        if (more) store_tile(cur ^ 1);           // ds_writes issue in the shadow of the second half's MFMAs
+        compute_tile(cur, BK / 2, BK);
         __syncthreads();
     }
 
@@ -255,27 +269,26 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     }
 }
 
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+static void launch_layout(const GemmArgs& g, bool va, bool vb) {
+    dim3 grid(g.nwg), block(WM * WN * 64);
+    hipStream_t s = rt().stream;
+    if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true>), grid, block, 0, s, g);
+    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false>), grid, block, 0, s, g);
+    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true>), grid, block, 0, s, g);
+    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false>), grid, block, 0, s, g);
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
-static void launch_config(const GemmArgs& base, bool akc, bool bkc, bool vec, int64_t batch) {
+static void launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
     GemmArgs g = base;
     g.tiles_m = int((g.M + BM - 1) / BM);
     g.tiles_n = int((g.N + BN - 1) / BN);
     g.nwg = int(int64_t(g.tiles_m) * g.tiles_n * batch);
-    dim3 grid(g.nwg), block(WM * WN * 64);
-    hipStream_t s = rt().stream;
-#define LG_GEMM_LAUNCH(AK, BKc, V) hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AK, BKc, V>), grid, block, 0, s, g)
-    if (vec) {
-        if (akc && bkc) LG_GEMM_LAUNCH(true, true, true);
-        else if (akc) LG_GEMM_LAUNCH(true, false, true);
-        else if (bkc) LG_GEMM_LAUNCH(false, true, true);
-        else LG_GEMM_LAUNCH(false, false, true);
-    } else {
-        if (akc && bkc) LG_GEMM_LAUNCH(true, true, false);
-        else if (akc) LG_GEMM_LAUNCH(true, false, false);
-        else if (bkc) LG_GEMM_LAUNCH(false, true, false);
-        else LG_GEMM_LAUNCH(false, false, false);
-    }
-#undef LG_GEMM_LAUNCH
+    if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true>(g, va, vb);
+    else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false>(g, va, vb);
+    else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true>(g, va, vb);
+    else            launch_layout<BM, BN, BK, WM, WN, false, false>(g, va, vb);
 }
 
 }  // namespace lg
@@ -315,17 +328,17 @@ extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     auto vec_ok = [](const float* p, int64_t ld, int64_t bstride, int64_t contiguous_extent) {
         return aligned16(p) && ld % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0;
     };
-    const bool vec = vec_ok(A, lda, strideA, akc ? K : M) && vec_ok(B, ldb, strideB, bkc ? K : N);
+    const bool va = vec_ok(A, lda, strideA, akc ? K : M), vb = vec_ok(B, ldb, strideB, bkc ? K : N);
 
     // tile choice: largest tile that still yields enough workgroups for 256 CUs
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     LG_ARG(nblocks(32, 32) < (int64_t(1) << 30), "lg_gemm_f32: problem too large for one launch");
     if (N <= 32) {
-        launch_config<64, 32, 32, 2, 1>(g, akc, bkc, vec, batch);
+        launch_config<64, 32, 32, 2, 1>(g, akc, bkc, va, vb, batch);
     } else if (nblocks(128, 128) >= 384 || (M >= 2048 && N >= 2048)) {
-        launch_config<128, 128, 32, 2, 2>(g, akc, bkc, vec, batch);
+        launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     } else {
-        launch_config<64, 64, 32, 2, 2>(g, akc, bkc, vec, batch);
+        launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     }
     LG_CHECK_LAUNCH();
     return LG_OK;

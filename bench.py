@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--matmul-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
+    ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
+                    help="graph: the step's kernels are captured once in hipGraphs and replayed; eager: python tape every step")
     return ap.parse_args()
 
 
@@ -84,7 +86,9 @@ def main():
     np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
     model = MLP().map_parameters(lambda p: p.hip())
     dp = DataParallel(model.parameters(), comm)
-    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale)
+    use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
+    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
+                                device_step=use_graph)
     rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
     x = HipTensor.from_numpy(rng.uniform(0, 1, (1024, 784)).astype(np.float32))
     labels = rng.randint(0, 10, 1024)
@@ -92,13 +96,49 @@ def main():
     onehot_np[np.arange(1024), labels] = 1
     onehot = HipTensor.from_numpy(onehot_np)
 
-    def step():
+    def forward_backward():
         loss = light.loss.mse(model(x), onehot)
         opt.zero_grad()
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = forward_backward()
         dp.sync_gradients()
         opt.step()
         return loss
+
+    step = eager_step
+    if use_graph:
+        from lightgrad_amd.autograd.hip import HipGraph
+        for _ in range(3):                       # eager: allocates optimizer state, fills the pool, loads kernels
+            eager_step()
+        n_params = len(opt.parameters)
+        if world == 1:
+            g_all = HipGraph()
+            with g_all.capture():
+                graph_loss = eager_step()
+            opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
+
+            def step():
+                g_all.replay()
+                opt.on_graph_replay()
+                return graph_loss
+        else:
+            # the RCCL all-reduce stays an eager call between two graphs (forward+backward | optimizer)
+            g_fb, g_opt = HipGraph(), HipGraph()
+            with g_fb.capture():
+                graph_loss = forward_backward()
+            with g_opt.capture():
+                opt.step()
+            opt.t -= n_params
+
+            def step():
+                g_fb.replay()
+                dp.sync_gradients()
+                g_opt.replay()
+                opt.on_graph_replay()
+                return graph_loss
 
     for _ in range(args.warmup):
         loss = step()
@@ -235,7 +275,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
                        "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
-                       "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused", "dispatch": "eager python tape",
+                       "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
+                       "dispatch": "hipGraph replay (python tape captured once)" if use_graph else "eager python tape",
                        "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "final_loss": round(final_loss, 6),
             "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),

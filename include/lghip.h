@@ -192,6 +192,14 @@ int lg_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
                      double lr, double b1, double b2, double eps,
                      double inv_bias1, double inv_bias2, double gscale, int belief);
 
+/* Graph-safe form: the optimizer step number is read from device memory (t = *step * t_mul + t_add,
+ * the reference's per-PARAMETER `t`, optim.py:36/:48), so a captured hipGraph stays correct when
+ * replayed; lg_counter_add_i64 advances the counter inside the same graph. */
+int lg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                         double lr, double b1, double b2, double eps,
+                         const int64_t* step, int64_t t_mul, int64_t t_add, double gscale, int belief);
+int lg_counter_add_i64(int64_t* counter, int64_t delta);
+
 /* library build info: "liblghip <version> gfx950 <build date>" */
 const char* lg_version(void);
 

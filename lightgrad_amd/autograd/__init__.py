@@ -6,7 +6,7 @@ from .grads import Gradients
 from .func import Function, WrapperFunction
 from .tensor import AbstractTensor
 from .cpu import CpuTensor
-from .hip import HipTensor, HipDevice
+from .hip import HipTensor, HipDevice, HipGraph
 
 Tensor = CpuTensor      # default backend, as in the reference (autograd/__init__.py:9)
 no_grad = Gradients.no_grad

@@ -65,6 +65,9 @@ PROTOTYPES = {
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_double, c_int]),
+    "lg_adam_step_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
+                                     c_double, c_void_p, c_int64, c_int64, c_double, c_int]),
+    "lg_counter_add_i64": (c_int, [c_void_p, c_int64]),
 }
 
 COMM_PROTOTYPES = {

@@ -215,6 +215,22 @@ class HipTensor(AbstractTensor):
         from .ops import adam_step_
         adam_step_(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief)
 
+    @staticmethod
+    def _new_step_counter(step: int) -> "HipTensor":
+        """device-resident optimizer step number (int64) for graph-captured training steps"""
+        return HipTensor.from_numpy(np.asarray([step], dtype=np.int64), requires_grad=False)
+
+    def _fused_adam_step_dev(self, grad, m, v, lr, b1, b2, eps, step_counter, t_mul, t_add, grad_scale, belief):
+        """like `_fused_adam_step`, but t = step_counter * t_mul + t_add is evaluated on the device"""
+        for t in (self, grad, m, v):
+            assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
+        _l.check(_l.lib().lg_adam_step_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, self.numel(), lr, b1, b2, eps,
+                                               step_counter.ptr, t_mul, t_add, grad_scale, 1 if belief else 0))
+
+    @staticmethod
+    def _advance_step_counter(step_counter, delta: int = 1) -> None:
+        _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, delta))
+
     def __repr__(self):
         return "HipTensor(shape=%s, strides=%s, dtype=%s)" % (self._shape, self._strides, self._dtype)
 

@@ -73,3 +73,49 @@ extern "C" int lg_adam_step_f32(float* p, const float* g, float* m, float* v, in
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
+
+// ---- graph-safe variant: the step number lives in device memory ---------------------------------
+// A captured hipGraph replays fixed kernel arguments, so the bias corrections 1/(1 - b^t) cannot be
+// host scalars.  Here t = *step * t_mul + t_add is read on the device (the reference advances `t`
+// once per PARAMETER, optim.py:36/:48: parameter i of P at optimizer step s has t = s*P + i + 1) and
+// the corrections are formed in double like the python expression, then rounded once to fp32.
+namespace lg {
+
+__global__ void __launch_bounds__(256) adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                float* __restrict__ v, int64_t n, AdamScalars c, const int64_t* __restrict__ step,
+                                                int64_t t_mul, int64_t t_add, double b1, double b2) {
+    const double t = double(step[0] * t_mul + t_add);
+    c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
+    c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(p[i], g[i], m[i], v[i], c);
+}
+
+__global__ void counter_add(int64_t* counter, int64_t delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += delta;
+}
+
+}  // namespace lg
+
+extern "C" int lg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2,
+                                    double eps, const int64_t* step, int64_t t_mul, int64_t t_add, double gscale, int belief) {
+    LG_REQUIRE_INIT();
+    LG_ARG(n >= 0, "lg_adam_step_dev_f32: negative length");
+    if (n == 0) return LG_OK;
+    LG_ARG(p && g && m && v && step, "lg_adam_step_dev_f32: NULL pointer");
+    AdamScalars c;
+    c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
+    c.eps = float(eps); c.inv_bias1 = 0.f; c.inv_bias2 = 0.f; c.gscale = float(gscale); c.belief = belief;
+    c.scale_grad = gscale != 1.0;
+    hipLaunchKernelGGL(adam_dev, dim3(stream_grid(n)), dim3(256), 0, rt().stream, p, g, m, v, n, c, step, t_mul, t_add, b1, b2);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_counter_add_i64(int64_t* counter, int64_t delta) {
+    LG_REQUIRE_INIT();
+    LG_ARG(counter != nullptr, "lg_counter_add_i64: NULL pointer");
+    hipLaunchKernelGGL(counter_add, dim3(1), dim3(64), 0, rt().stream, counter, delta);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

@@ -52,7 +52,7 @@ class Adam(Optimizer):
     belief = False
 
     def __init__(self, parameters, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                 fused: bool = False, grad_scale: float = 1.0):
+                 fused: bool = False, grad_scale: float = 1.0, device_step: bool = False):
         Optimizer.__init__(self, parameters)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.t = 0
@@ -60,7 +60,10 @@ class Adam(Optimizer):
         self.v = [0] * len(self.parameters)
         # fused: use the backend's one-kernel update when the tensor class offers `_fused_adam_step`
         # grad_scale: factor applied to every gradient first (1/world_size in data-parallel training)
-        self.fused, self.grad_scale = fused, grad_scale
+        # device_step (needs fused): the step counter behind the bias corrections lives in device memory, so the
+        # whole training step can be captured in a hipGraph and replayed (autograd/hip/graph.py)
+        self.fused, self.grad_scale, self.device_step = fused, grad_scale, device_step
+        self._step_counter = None
 
     @Gradients.no_grad()
     def step(self) -> None:
@@ -74,8 +77,20 @@ class Adam(Optimizer):
             if not isinstance(self.m[i], AbstractTensor):
                 self.m[i] = p.__class__.zeros(p.shape, requires_grad=False)
                 self.v[i] = p.__class__.zeros(p.shape, requires_grad=False)
-            kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
-                   (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
+            if self.device_step:
+                if self._step_counter is None:
+                    self._step_counter = p._new_step_counter((self.t - 1) // len(self.parameters))
+                p._fused_adam_step_dev(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
+                                       self._step_counter, len(self.parameters), i + 1, self.grad_scale, self.belief)
+            else:
+                kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
+                       (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
+        if self._step_counter is not None:
+            self.parameters[0]._advance_step_counter(self._step_counter)
+
+    def on_graph_replay(self, n: int = 1) -> None:
+        """keep the host-side step count in line after `n` replays of a captured step"""
+        self.t += n * len(self.parameters)
 
     def second_moment_input(self, grad, m):
         return grad

@@ -1,0 +1,80 @@
+"""hipGraph capture/replay of the training step and the graph-safe (device-resident step counter)
+optimizer: replays must reproduce the reference trajectory exactly like the eager tape does."""
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from conftest import load_golden
+import np_oracle as O
+from test_cpu_backend import MLP
+
+pytestmark = pytest.mark.gpu
+
+
+def build(hip, g, opt_name, **kw):
+    d_in, d_hid, d_out, batch, steps, seed = (int(v) for v in g["config"])
+    model = MLP(d_in, d_hid, d_out)
+    model.load_parameters({n: g["w0/" + n] for n in O.PARAM_ORDER})
+    model.map_parameters(lambda p: p.hip())
+    onehot = np.zeros((batch, d_out), np.float32)
+    onehot[np.arange(batch), g["labels"]] = 1
+    cls = {"adabelief": light.optim.AdaBelief, "adam": light.optim.Adam}[opt_name]
+    opt = cls(model.parameters(), lr=1e-3, fused=True, **kw)
+    x, t = hip.from_numpy(g["x"]), hip.from_numpy(onehot)
+
+    def step():
+        l = light.loss.mse(model(x), t)
+        opt.zero_grad()
+        l.backward()
+        opt.step()
+        return l
+    return model, opt, step, steps
+
+
+@pytest.mark.parametrize("opt_name", ["adabelief", "adam"])
+def test_device_step_counter_equals_host_scalars(hip, opt_name):
+    g = load_golden("mlp_small_%s.npz" % opt_name)
+    model, opt, step, steps = build(hip, g, opt_name, device_step=True)
+    losses = [step().item() for _ in range(steps)]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    assert opt.t == steps * 4 and int(opt._step_counter.numpy()[0]) == steps
+
+
+def test_graph_replay_reproduces_reference_trajectory(hip):
+    from lightgrad_amd.autograd.hip import HipGraph, HipDevice
+    g = load_golden("mlp_small_adabelief.npz")
+    model, opt, step, steps = build(hip, g, "adabelief", device_step=True)
+    losses = [step().item() for _ in range(2)]                 # eager warm-up: steps 0 and 1
+    graph = HipGraph()
+    with graph.capture():
+        loss = step()                                          # recorded, not executed
+    opt.t -= 4                                                 # the capture pass ran the python bookkeeping, not the kernels
+    for _ in range(steps - 2):
+        graph.replay()
+        opt.on_graph_replay()
+        losses.append(loss.item())                             # static output tensor of the graph
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    assert opt.t == steps * 4
+    before = HipDevice.pool_stats()["in_use_bytes"]
+    graph.destroy()
+    del loss
+    assert HipDevice.pool_stats()["in_use_bytes"] <= before
+
+
+def test_capture_rejects_host_transfers(hip):
+    from lightgrad_amd.autograd.hip import HipGraph, HipError
+    a = hip.from_numpy(np.ones((4, 4), np.float32))
+    graph = HipGraph()
+    with pytest.raises(HipError, match="cannot be captured"):
+        with graph.capture():
+            (a + a).numpy()
+    # the library left capture mode cleanly: normal work continues
+    np.testing.assert_array_equal((a + a).numpy(), np.full((4, 4), 2, np.float32))
+    g2 = HipGraph()
+    with g2.capture():
+        b = a * 3.0
+    g2.replay()
+    np.testing.assert_array_equal(b.numpy(), np.full((4, 4), 3, np.float32))

@@ -34,8 +34,13 @@ struct GemmArgs {
     int64_t lda, ldb, ldc;
     int64_t sA, sB, sC;     // batch strides (elements)
     int     tiles_m, tiles_n;
-    int     nwg;            // tiles_m * tiles_n * batch
+    int     nwg;            // tiles_m * tiles_n * batch * k_slices
     int     accumulate;
+    // split-K: slice s of k_slices handles k in [s*k_per_slice, min(K, (s+1)*k_per_slice)) and writes its partial
+    // product to W + (batch*k_slices + s)*M*N (dense, ld = N); splitk_combine sums the slices in a fixed order
+    int     k_slices;
+    int64_t k_per_slice;    // multiple of BK
+    float*  W;
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -71,8 +76,9 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     // tile coordinates
     const int id = xcd_remap(blockIdx.x, g.nwg);
     const int per_batch = g.tiles_m * g.tiles_n;
-    const int batch = id / per_batch;
-    const int t = id - batch * per_batch;
+    const int bs = id / per_batch;                 // (batch, k-slice) pair
+    const int batch = bs / g.k_slices, slice = bs - batch * g.k_slices;
+    const int t = id - bs * per_batch;
     // grouped order: consecutive ids walk GROUP_M tile rows before moving to the next tile column, so the
     // ~64 workgroups resident on one XCD at a time cover a near-square patch of C and share both their
     // A row-panels and their B column-panels in that XCD's 4 MiB L2
@@ -84,7 +90,11 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
     const float* __restrict__ A = g.A + int64_t(batch) * g.sA;
     const float* __restrict__ B = g.B + int64_t(batch) * g.sB;
-    float* __restrict__ C = g.C + int64_t(batch) * g.sC;
+    float* __restrict__ C = g.k_slices > 1 ? g.W + int64_t(bs) * g.M * g.N : g.C + int64_t(batch) * g.sC;
+    const int64_t ldc = g.k_slices > 1 ? g.N : g.ldc;
+    const int accumulate = g.k_slices > 1 ? 0 : g.accumulate;
+    const int64_t k_begin = int64_t(slice) * g.k_per_slice;
+    const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
 
     float ra[A_ELEMS], rb[B_ELEMS];   // staging registers
 
@@ -96,11 +106,11 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (AKC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
-                    if (m0 + row < g.M && k0 + kq * 4 < g.K)
+                    if (m0 + row < g.M && k0 + kq * 4 < k_end)
                         v = *reinterpret_cast<const float4*>(A + (m0 + row) * g.lda + k0 + kq * 4);
                 } else {
                     const int kk = f / (BM / 4), mq = f % (BM / 4);
-                    if (k0 + kk < g.K && m0 + mq * 4 < g.M)
+                    if (k0 + kk < k_end && m0 + mq * 4 < g.M)
                         v = *reinterpret_cast<const float4*>(A + (k0 + kk) * g.lda + m0 + mq * 4);
                 }
                 ra[4 * i] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
@@ -112,10 +122,10 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 float v = 0.f;
                 if constexpr (AKC) {
                     const int row = e / BK, kk = e % BK;
-                    if (m0 + row < g.M && k0 + kk < g.K) v = A[(m0 + row) * g.lda + k0 + kk];
+                    if (m0 + row < g.M && k0 + kk < k_end) v = A[(m0 + row) * g.lda + k0 + kk];
                 } else {
                     const int kk = e / BM, mm = e % BM;
-                    if (k0 + kk < g.K && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
+                    if (k0 + kk < k_end && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
                 }
                 ra[i] = v;
             }
@@ -127,11 +137,11 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (BKC) {
                     const int row = f / (BK / 4), kq = f % (BK / 4);
-                    if (n0 + row < g.N && k0 + kq * 4 < g.K)
+                    if (n0 + row < g.N && k0 + kq * 4 < k_end)
                         v = *reinterpret_cast<const float4*>(B + (n0 + row) * g.ldb + k0 + kq * 4);
                 } else {
                     const int kk = f / (BN / 4), nq = f % (BN / 4);
-                    if (k0 + kk < g.K && n0 + nq * 4 < g.N)
+                    if (k0 + kk < k_end && n0 + nq * 4 < g.N)
                         v = *reinterpret_cast<const float4*>(B + (k0 + kk) * g.ldb + n0 + nq * 4);
                 }
                 rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
@@ -143,10 +153,10 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 float v = 0.f;
                 if constexpr (BKC) {
                     const int row = e / BK, kk = e % BK;
-                    if (n0 + row < g.N && k0 + kk < g.K) v = B[(n0 + row) * g.ldb + k0 + kk];
+                    if (n0 + row < g.N && k0 + kk < k_end) v = B[(n0 + row) * g.ldb + k0 + kk];
                 } else {
                     const int kk = e / BN, nn = e % BN;
-                    if (k0 + kk < g.K && n0 + nn < g.N) v = B[(k0 + kk) * g.ldb + n0 + nn];
+                    if (k0 + kk < k_end && n0 + nn < g.N) v = B[(k0 + kk) * g.ldb + n0 + nn];
                 }
                 rb[i] = v;
             }
@@ -234,14 +244,14 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         }
     };
 
-    const int64_t nkt = (g.K + BK - 1) / BK;
-    load_tile(0);
+    const int64_t nkt = (k_end - k_begin + BK - 1) / BK;
+    load_tile(k_begin);
     store_tile(0);
     __syncthreads();
     for (int64_t kt = 0; kt < nkt; ++kt) {
         const int cur = int(kt & 1);
         const bool more = kt + 1 < nkt;
-        if (more) load_tile((kt + 1) * BK);      // in flight during the MFMAs below
+        if (more) load_tile(k_begin + (kt + 1) * BK);      // in flight during the MFMAs below
         compute_tile(cur, 0, BK / 2);
         if (more) store_tile(cur ^ 1);           // ds_writes issue in the shadow of the second half's MFMAs
         compute_tile(cur, BK / 2, BK);
@@ -260,12 +270,28 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
                     if (row < g.M) {
-                        float* p = C + row * g.ldc + col;
-                        *p = g.accumulate ? *p + acc[i][j][e] : acc[i][j][e];
+                        float* p = C + row * ldc + col;
+                        *p = accumulate ? *p + acc[i][j][e] : acc[i][j][e];
                     }
                 }
             }
         }
+    }
+}
+
+// C[b][m][n] (+)= sum_s W[b][s][m][n], slices added in index order (deterministic)
+__global__ void __launch_bounds__(256) splitk_combine(const float* __restrict__ W, float* __restrict__ C, int64_t M, int64_t N,
+                                                      int64_t ldc, int64_t sC, int slices, int64_t total, int accumulate) {
+    const int64_t mn = M * N;
+    int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / mn, r = e - b * mn;
+        const int64_t m = r / N, n = r - m * N;
+        const float* w = W + b * slices * mn + r;
+        float acc = w[0];
+        for (int s = 1; s < slices; ++s) acc += w[int64_t(s) * mn];
+        float* c = C + b * sC + m * ldc + n;
+        *c = accumulate ? *c + acc : acc;
     }
 }
 
@@ -280,15 +306,40 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-static void launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
+static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
     GemmArgs g = base;
     g.tiles_m = int((g.M + BM - 1) / BM);
     g.tiles_n = int((g.N + BN - 1) / BN);
-    g.nwg = int(int64_t(g.tiles_m) * g.tiles_n * batch);
+    const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n * batch;
+    // split-K when the tile grid alone cannot fill 256 CUs: aim at >= 512 workgroups, keep >= 2 K-tiles per slice
+    int64_t slices = 1;
+    if (tiles < 256 && g.K >= 4 * BK) {
+        slices = (512 + tiles - 1) / tiles;
+        const int64_t max_slices = g.K / (2 * BK);
+        if (slices > max_slices) slices = max_slices;
+        if (slices > 64) slices = 64;
+        if (slices < 1) slices = 1;
+    }
+    g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;
+    slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
+    g.k_slices = int(slices);
+    g.nwg = int(tiles * slices);
+    g.W = nullptr;
+    if (slices > 1) {
+        int rc = lg_malloc(reinterpret_cast<void**>(&g.W), size_t(batch * slices * g.M * g.N) * sizeof(float));
+        if (rc != LG_OK) return rc;
+    }
     if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true>(g, va, vb);
     else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false>(g, va, vb);
     else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true>(g, va, vb);
     else            launch_layout<BM, BN, BK, WM, WN, false, false>(g, va, vb);
+    if (slices > 1) {
+        const int64_t total = batch * g.M * g.N;
+        hipLaunchKernelGGL(splitk_combine, dim3(stream_grid(total)), dim3(256), 0, rt().stream, g.W, g.C, g.M, g.N, g.ldc, g.sC,
+                           g.k_slices, total, g.accumulate);
+        return lg_free(g.W);     // stream-ordered: reused only by later launches
+    }
+    return LG_OK;
 }
 
 }  // namespace lg
@@ -333,13 +384,17 @@ extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     // tile choice: largest tile that still yields enough workgroups for 256 CUs
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     LG_ARG(nblocks(32, 32) < (int64_t(1) << 30), "lg_gemm_f32: problem too large for one launch");
+    int rc;
     if (N <= 32) {
-        launch_config<64, 32, 32, 2, 1>(g, akc, bkc, va, vb, batch);
+        rc = launch_config<64, 32, 32, 2, 1>(g, akc, bkc, va, vb, batch);
+    } else if (M <= 32) {
+        rc = launch_config<32, 64, 32, 1, 2>(g, akc, bkc, va, vb, batch);
     } else if (nblocks(128, 128) >= 384 || (M >= 2048 && N >= 2048)) {
-        launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch);
+        rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     } else {
-        launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
+        rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     }
+    if (rc != LG_OK) return rc;
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

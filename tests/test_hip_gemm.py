@@ -13,7 +13,7 @@ def rel_err(got, ref64):
     return np.linalg.norm(got.astype(np.float64) - ref64) / max(np.linalg.norm(ref64), 1e-30)
 
 
-SHAPES = [(1, 1, 1), (1, 7, 1), (3, 5, 2), (32, 32, 32), (33, 31, 35), (64, 64, 64), (65, 129, 67), (128, 128, 128),
+SHAPES = [(16, 3000, 24), (8, 640, 700), (1, 1, 1), (1, 7, 1), (3, 5, 2), (32, 32, 32), (33, 31, 35), (64, 64, 64), (65, 129, 67), (128, 128, 128),
           (127, 255, 96), (256, 100, 256), (1024, 784, 512), (1024, 512, 10), (1024, 10, 512), (784, 1024, 512), (10, 1024, 512),
           (200, 36, 300), (130, 8, 70), (512, 4, 512), (257, 130, 513)]
 
@@ -103,6 +103,19 @@ def test_c_abi_accumulate_and_errors(hip):
     ta, tb, tc = hip.from_numpy(a), hip.from_numpy(b), hip.from_numpy(c)
     assert lib.lg_gemm_f32(0, 0, M, N, K, ta.ptr, K, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 1) == 0
     np.testing.assert_allclose(tc.numpy(), c + a.astype(np.float64) @ b, rtol=1e-5, atol=1e-5)
+    # split-K path (few tiles, long K) with accumulate and a padded ldc
+    M2, K2, N2, ldc = 96, 4096, 80, 96
+    a2, b2 = rng.uniform(-1, 1, (M2, K2)).astype(np.float32), rng.uniform(-1, 1, (K2, N2)).astype(np.float32)
+    c2 = rng.uniform(-1, 1, (M2, ldc)).astype(np.float32)
+    ta2, tb2, tc2 = hip.from_numpy(a2), hip.from_numpy(b2), hip.from_numpy(c2)
+    assert lib.lg_gemm_f32(0, 0, M2, N2, K2, ta2.ptr, K2, 0, tb2.ptr, N2, 0, tc2.ptr, ldc, 0, 1, 1) == 0
+    expect = c2.astype(np.float64)
+    expect[:, :N2] += a2.astype(np.float64) @ b2
+    assert rel_err(tc2.numpy(), expect) <= 1e-5
+    np.testing.assert_array_equal(tc2.numpy()[:, N2:], c2[:, N2:])          # padding columns untouched
+    again = hip.from_numpy(c2)
+    assert lib.lg_gemm_f32(0, 0, M2, N2, K2, ta2.ptr, K2, 0, tb2.ptr, N2, 0, again.ptr, ldc, 0, 1, 1) == 0
+    np.testing.assert_array_equal(again.numpy(), tc2.numpy())                # deterministic slice order
     assert lib.lg_gemm_f32(0, 0, M, N, K, ta.ptr, K - 1, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 0) == -1       # lda < K
     assert b"leading dimension" in lib.lg_last_error()
     assert lib.lg_gemm_f32(0, 0, M, N, K, None, K, 0, tb.ptr, N, 0, tc.ptr, N, 0, 1, 0) == -1

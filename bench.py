@@ -85,10 +85,12 @@ def main():
 
     np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
     model = MLP().map_parameters(lambda p: p.hip())
-    dp = DataParallel(model.parameters(), comm)
     use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
+    dp = DataParallel(model.parameters(), comm, flatten=use_graph)
     opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
                                 device_step=use_graph)
+    if use_graph:
+        dp.attach(opt)                               # flat buckets: zero_grad = one fill, update = one launch
     rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
     x = HipTensor.from_numpy(rng.uniform(0, 1, (1024, 784)).astype(np.float32))
     labels = rng.randint(0, 10, 1024)

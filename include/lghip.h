@@ -178,6 +178,15 @@ int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 float* C, int64_t ldc, int64_t strideC,
                 int64_t batch, int accumulate);
 
+/* Same product with a bias row added in the epilogue: C[b][m][n] = (op(A[b]) @ op(B[b]))[m][n] + bias[n]
+ * (bias may be NULL).  The sum is rounded to fp32 before the bias is added, exactly like the separate
+ * `x @ W.T + b` of nn.Linear (nn.py:96).  Fuses one elementwise pass per Linear layer. */
+int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                     const float* A, int64_t lda, int64_t strideA,
+                     const float* B, int64_t ldb, int64_t strideB,
+                     float* C, int64_t ldc, int64_t strideC,
+                     int64_t batch, const float* bias);
+
 /* ---- fused optimizer ---------------------------------
  * One Adam/AdaBelief update of a contiguous parameter, numerically the
  * expression sequence of optim.py:36-40 / :48-52 evaluated per element (one
@@ -199,6 +208,19 @@ int lg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n
                          double lr, double b1, double b2, double eps,
                          const int64_t* step, int64_t t_mul, int64_t t_add, double gscale, int belief);
 int lg_counter_add_i64(int64_t* counter, int64_t delta);
+
+/* All parameters of a model in one launch: p, g, m, v are flat buckets holding `nseg` (<= 64) parameters
+ * back to back, parameter j occupying [offsets[j], offsets[j+1]); its step number is
+ * t = *step * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32. */
+int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
+                          double lr, double b1, double b2, double eps,
+                          const int64_t* step, double gscale, int belief);
+
+/* ---- fused loss ----------------------------------------
+ * loss.mse forward (loss.py:4-10) for dense fp32 tensors of n elements:
+ *   err[i] = y[i] + (-y_hat[i]);   loss[0] = (sum_i err[i]^2 * (1/n)) * 0.5
+ * `err` is what mse.backward multiplies by the upstream gradient (loss.py:11-12). */
+int lg_mse_f32(const float* y, const float* y_hat, float* err, float* loss, int64_t n);
 
 /* library build info: "liblghip <version> gfx950 <build date>" */
 const char* lg_version(void);

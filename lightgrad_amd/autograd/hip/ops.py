@@ -285,8 +285,8 @@ def _collapse_batch(shape, strides):
     return n, st
 
 
-def _gemm(a, b, out_colmajor=False):
-    """a (..., M, K) @ b (..., K, N) -> (..., M, N) on the MFMA SGEMM kernel.
+def _gemm(a, b, out_colmajor=False, bias=None):
+    """a (..., M, K) @ b (..., K, N) [+ bias (N,)] -> (..., M, N) on the MFMA SGEMM kernel.
 
     Operands are consumed in place whenever one of their last two dims has stride 1
     (row-major or stride-permuted views alike).  `out_colmajor` stores the result
@@ -313,7 +313,7 @@ def _gemm(a, b, out_colmajor=False):
             lead = _collapse_batch(a._shape[:-1], a._strides[:-1])
         rows, rstride = lead
         flat = HipTensor(a.data, (rows, K), (rstride if rows > 1 else K, a._strides[-1]), a._offset, a._dtype)
-        out = _gemm(flat, b, out_colmajor=False)
+        out = _gemm(flat, b, out_colmajor=False, bias=bias)
         return out.reshape(*batch_shape, M, N)
 
     ma, mb = _as_mat(a), _as_mat(b)
@@ -337,8 +337,14 @@ def _gemm(a, b, out_colmajor=False):
 
     L = _l.lib()
 
+    if bias is not None:
+        assert not out_colmajor and bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32
+
     def launch(pa, pb, po, count, stra, strb, stro):
-        if out_colmajor:
+        if bias is not None:
+            _l.check(L.lg_gemm_bias_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
+                                        pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, bias.ptr))
+        elif out_colmajor:
             # C^T (N x M, row-major) = B^T @ A^T : swap the operands and flip their layouts
             _l.check(L.lg_gemm_f32(0 if mb.colmajor else 1, 0 if ma.colmajor else 1, N, M, K,
                                    pb, mb.ld, strb, pa, ma.ld, stra, po, M, stro, count, 0))
@@ -635,7 +641,39 @@ max = HipTensor.register_op("max", _extremum("max", _l.RED_MAX, "every tied maxi
 min = HipTensor.register_op("min", _extremum("min", _l.RED_MIN, "cpu/ops.py:274-286"))
 
 
-""" Fused forms used by nn / optim (SURVEY.md §8f row 1) """
+""" Fused forms used by nn / optim / loss (SURVEY.md §8f row 1) """
+
+
+@HipTensor.register_op()
+class linear(Function):
+    """ nn.Linear in one tape node: `x @ W.T(1, 0) + b` (nn.py:90-96) with the bias added in the GEMM epilogue.
+    Same values as the three-op form (transpose view, dot, broadcast add): the product is rounded to fp32 before the
+    bias is added.  backward: dx = g @ W, dW = g^T @ x (dense, in W's own layout), db = column sums of g - what
+    dot.backward + transpose.backward + the un-broadcast of func.py:50-56 produce. """
+    def forward(ctx, x, weight, bias=None):
+        ctx.save_for_backward(x, weight, bias is not None)
+        return _gemm(x, _swap_last(weight), bias=bias)
+
+    def backward(ctx, out_grad):
+        x, weight, has_bias = ctx.get_saved_tensors()
+        out_f = weight._shape[0]
+        g2 = out_grad.reshape(-1, out_f)
+        x2 = x.reshape(-1, x._shape[-1])
+        dw = _gemm(_swap_last(g2), x2) if weight.requires_grad else None
+        dx = _gemm(g2, weight).reshape(*x._shape) if x.requires_grad else None
+        if not has_bias:
+            return dx, dw
+        return dx, dw, _reduce(_l.RED_SUM, g2, (0,), False)
+
+
+def mse_forward(y, y_hat):
+    """fused loss.mse forward: returns (loss of shape (), err = y - y_hat) from one pass (lg_mse_f32)"""
+    _require_f32(y, y_hat)
+    assert y._shape == y_hat._shape, "mse: shapes %s and %s differ" % (y._shape, y_hat._shape)
+    y, y_hat = y.contiguous(), y_hat.contiguous()
+    err, loss = HipTensor.empty(y._shape), HipTensor.empty(())
+    _l.check(_l.lib().lg_mse_f32(y.ptr, y_hat.ptr, err.ptr, loss.ptr, y.numel()))
+    return loss, err
 
 
 def adam_step_(p, g, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, gscale=1.0, belief=False):

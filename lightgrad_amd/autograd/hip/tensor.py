@@ -215,6 +215,19 @@ class HipTensor(AbstractTensor):
         from .ops import adam_step_
         adam_step_(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief)
 
+    def _fused_mse(self, y_hat):
+        """optional loss hook (loss.mse): (loss, err) from one kernel instead of seven tape ops"""
+        from .ops import mse_forward
+        return mse_forward(self, y_hat)
+
+    def _fused_adam_multi_dev(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
+        """self/grad/m/v are flat buckets holding len(offsets)-1 parameters: ONE launch updates them all"""
+        for t in (self, grad, m, v):
+            assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
+        assert offsets[-1] == self.numel()
+        _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
+                                                lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0))
+
     @staticmethod
     def _new_step_counter(step: int) -> "HipTensor":
         """device-resident optimizer step number (int64) for graph-captured training steps"""

@@ -36,6 +36,7 @@ struct GemmArgs {
     int     tiles_m, tiles_n;
     int     nwg;            // tiles_m * tiles_n * batch * k_slices
     int     accumulate;
+    const float* bias;      // optional [N]: added to every row of the product (nn.Linear's `+ b`, nn.py:96)
     // split-K: slice s of k_slices handles k in [s*k_per_slice, min(K, (s+1)*k_per_slice)) and writes its partial
     // product to W + (batch*k_slices + s)*M*N (dense, ld = N); splitk_combine sums the slices in a fixed order
     int     k_slices;
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     float* __restrict__ C = g.k_slices > 1 ? g.W + int64_t(bs) * g.M * g.N : g.C + int64_t(batch) * g.sC;
     const int64_t ldc = g.k_slices > 1 ? g.N : g.ldc;
     const int accumulate = g.k_slices > 1 ? 0 : g.accumulate;
+    const float* __restrict__ bias = g.k_slices > 1 ? nullptr : g.bias;   // split-K: the combine pass adds it once
     const int64_t k_begin = int64_t(slice) * g.k_per_slice;
     const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
 
@@ -266,12 +268,14 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             const int64_t col = n0 + (wn * TN + j) * 32 + r;
             const int64_t row0 = m0 + (wm * TM + i) * 32 + 4 * h;
             if (col < g.N) {
+                const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
                     if (row < g.M) {
                         float* p = C + row * ldc + col;
-                        *p = accumulate ? *p + acc[i][j][e] : acc[i][j][e];
+                        const float val = bias ? acc[i][j][e] + bv : acc[i][j][e];
+                        *p = accumulate ? *p + val : val;
                     }
                 }
             }
@@ -281,7 +285,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
 
 // C[b][m][n] (+)= sum_s W[b][s][m][n], slices added in index order (deterministic)
 __global__ void __launch_bounds__(256) splitk_combine(const float* __restrict__ W, float* __restrict__ C, int64_t M, int64_t N,
-                                                      int64_t ldc, int64_t sC, int slices, int64_t total, int accumulate) {
+                                                      int64_t ldc, int64_t sC, int slices, int64_t total, int accumulate,
+                                                      const float* __restrict__ bias) {
     const int64_t mn = M * N;
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -290,6 +295,7 @@ __global__ void __launch_bounds__(256) splitk_combine(const float* __restrict__ 
         const float* w = W + b * slices * mn + r;
         float acc = w[0];
         for (int s = 1; s < slices; ++s) acc += w[int64_t(s) * mn];
+        if (bias) acc += bias[n];
         float* c = C + b * sC + m * ldc + n;
         *c = accumulate ? *c + acc : acc;
     }
@@ -336,7 +342,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     if (slices > 1) {
         const int64_t total = batch * g.M * g.N;
         hipLaunchKernelGGL(splitk_combine, dim3(stream_grid(total)), dim3(256), 0, rt().stream, g.W, g.C, g.M, g.N, g.ldc, g.sC,
-                           g.k_slices, total, g.accumulate);
+                           g.k_slices, total, g.accumulate, g.bias);
         return lg_free(g.W);     // stream-ordered: reused only by later launches
     }
     return LG_OK;
@@ -346,11 +352,11 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
 
 using namespace lg;
 
-extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
-                           const float* A, int64_t lda, int64_t strideA,
-                           const float* B, int64_t ldb, int64_t strideB,
-                           float* C, int64_t ldc, int64_t strideC,
-                           int64_t batch, int accumulate) {
+static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                     const float* A, int64_t lda, int64_t strideA,
+                     const float* B, int64_t ldb, int64_t strideB,
+                     float* C, int64_t ldc, int64_t strideC,
+                     int64_t batch, int accumulate, const float* bias) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -360,6 +366,7 @@ extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
            "lg_gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld for M=%lld N=%lld K=%lld tA=%d tB=%d)",
            (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, transA, transB);
     if (K == 0) {
+        LG_ARG(bias == nullptr, "lg_gemm_bias_f32: K == 0 with a bias is not supported");
         if (accumulate) return LG_OK;
         // empty sum: C = 0
         int64_t shape[3] = {batch, M, N}, st[3] = {strideC, ldc, 1};
@@ -372,6 +379,7 @@ extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.accumulate = accumulate;
+    g.bias = bias;
 
     const bool akc = !transA;   // A[m*lda + k]: k is the contiguous index
     const bool bkc = transB != 0;   // B[n*ldb + k]
@@ -397,4 +405,20 @@ extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     if (rc != LG_OK) return rc;
     LG_CHECK_LAUNCH();
     return LG_OK;
+}
+
+extern "C" int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                           const float* A, int64_t lda, int64_t strideA,
+                           const float* B, int64_t ldb, int64_t strideB,
+                           float* C, int64_t ldc, int64_t strideC,
+                           int64_t batch, int accumulate) {
+    return gemm_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, accumulate, nullptr);
+}
+
+extern "C" int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                const float* A, int64_t lda, int64_t strideA,
+                                const float* B, int64_t ldb, int64_t strideB,
+                                float* C, int64_t ldc, int64_t strideC,
+                                int64_t batch, const float* bias) {
+    return gemm_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, 0, bias);
 }

@@ -119,3 +119,56 @@ extern "C" int lg_counter_add_i64(int64_t* counter, int64_t delta) {
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
+
+// ---- multi-tensor form: all parameters of a model in ONE launch --------------------------------
+// p, g, m, v are flat buckets holding nseg parameters back to back (offsets[j] .. offsets[j+1]);
+// blockIdx.y selects the parameter, whose step number is t = *step * nseg + j + 1 (optim.py:36/:48).
+namespace lg {
+
+constexpr int kMaxSegments = 64;
+struct AdamSegments {
+    int     nseg;
+    int64_t offsets[kMaxSegments + 1];
+};
+
+__global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, AdamSegments seg, AdamScalars c,
+                                                      const int64_t* __restrict__ step, double b1, double b2) {
+    const int j = blockIdx.y;
+    const int64_t begin = seg.offsets[j], n = seg.offsets[j + 1] - begin;
+    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t = double(step[0] * seg.nseg + j + 1);
+    c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
+    c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (; i < n; i += stride) adam_elem(p[begin + i], g[begin + i], m[begin + i], v[begin + i], c);
+}
+
+}  // namespace lg
+
+extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
+                                     double lr, double b1, double b2, double eps, const int64_t* step, double gscale,
+                                     int belief) {
+    LG_REQUIRE_INIT();
+    LG_ARG(nseg >= 1 && nseg <= kMaxSegments, "lg_adam_multi_dev_f32: %d segments (1..%d supported)", nseg, kMaxSegments);
+    LG_ARG(p && g && m && v && step && offsets, "lg_adam_multi_dev_f32: NULL pointer");
+    AdamSegments seg;
+    seg.nseg = nseg;
+    int64_t longest = 0;
+    for (int j = 0; j <= nseg; ++j) {
+        seg.offsets[j] = offsets[j];
+        if (j > 0) {
+            LG_ARG(offsets[j] >= offsets[j - 1], "lg_adam_multi_dev_f32: offsets must be non-decreasing");
+            if (offsets[j] - offsets[j - 1] > longest) longest = offsets[j] - offsets[j - 1];
+        }
+    }
+    if (longest == 0) return LG_OK;
+    AdamScalars c;
+    c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
+    c.eps = float(eps); c.inv_bias1 = 0.f; c.inv_bias2 = 0.f; c.gscale = float(gscale); c.belief = belief;
+    c.scale_grad = gscale != 1.0;
+    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid(longest), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

@@ -193,18 +193,37 @@ class DataParallel(object):
         optim.zero_grad(); loss.backward(); dp.sync_gradients(); optim.step()
     """
 
-    def __init__(self, parameters, comm: Communicator, broadcast_parameters: bool = True):
+    def __init__(self, parameters, comm: Communicator, broadcast_parameters: bool = True, flatten: bool = False):
         self.parameters = tuple(parameters)
         self.comm = comm
         assert len(self.parameters) > 0
         cls = self.parameters[0].__class__
-        self.bucket, views = _flat_and_views(cls, [p.shape for p in self.parameters])
+        shapes = [p.shape for p in self.parameters]
+        self.bucket, views = _flat_and_views(cls, shapes)
         for p, g in zip(self.parameters, views):
             assert p.requires_grad and p.dtype == np.float32
             p._grad = g           # zero_grad -> fill(0) and add_grad -> += both act in place on the view
         self.grad_scale = 1.0 / comm.world_size
+        self.offsets = tuple(int(o) for o in np.concatenate([[0], np.cumsum([p.numel() for p in self.parameters])]))
+        self.flat_parameters = None
+        if flatten:
+            # re-home the parameter VALUES into one bucket too (the tensor objects the model holds stay the same):
+            # lets the optimizer update every parameter with a single launch
+            assert issubclass(cls, HipTensor), "flatten=True needs the HipTensor backend"
+            self.flat_parameters, pviews = _flat_and_views(cls, shapes)
+            with Gradients.no_grad():
+                for p, v in zip(self.parameters, pviews):
+                    v[...] = p
+                    p._data, p._offset, p._strides = v._data, v._offset, v._strides
         if broadcast_parameters and comm.world_size > 1:
             self.broadcast_parameters()
+
+    def attach(self, optimizer):
+        """hand the flat buckets to an optimizer that can use them (one fill for zero_grad, one launch for step)"""
+        assert self.flat_parameters is not None, "DataParallel(..., flatten=True) first"
+        assert tuple(optimizer.parameters) == self.parameters
+        optimizer.use_flat_buckets(self.flat_parameters, self.bucket, self.offsets)
+        return optimizer
 
     def broadcast_parameters(self, root: int = 0):
         """make every replica start from rank `root`'s weights (one flat broadcast)"""

@@ -10,6 +10,12 @@ class mse(Function):
     """ Mean Squared Error """
 
     def forward(ctx, y, y_hat):
+        fused = getattr(y, "_fused_mse", None)
+        if fused is not None and y.shape == getattr(y_hat, "shape", None):
+            # optional backend hook: the expression below in one kernel (same roundings at the scaling steps)
+            loss, err = fused(y_hat)
+            ctx.save_for_backward(err)
+            return loss
         err = y - y_hat
         ctx.save_for_backward(err)
         return (err ** 2).mean() / 2

@@ -6,10 +6,16 @@ to each parameter in place under no_grad (optim.py:10-13); SGD with momentum
 is kept on purpose: `self.t` advances once per *parameter*, not once per step
 (optim.py:36, :48), so bias correction differs between parameters of one step.
 
-A backend may provide a fused update through the optional tensor method
-`_fused_adam_step(...)` (HipTensor does: one kernel per parameter instead of
-~14 elementwise launches - SURVEY.md §8f row 1); the expression form below is
-the definition and the fallback for every other backend.
+The expression form is the definition and runs on every backend.  Optional
+backend hooks (HipTensor implements them) replace it by
+kernels that evaluate the SAME expression sequence per element:
+  fused=True        one kernel per parameter instead of ~14 elementwise launches
+  device_step=True  the step number behind the bias corrections lives in device
+                    memory, so the whole training step can be captured in a
+                    hipGraph and replayed (autograd/hip/graph.py)
+  use_flat_buckets  parameters / gradients / moments live in flat buckets
+                    (dist.DataParallel(flatten=True)): zero_grad is one fill and
+                    the update of ALL parameters is one launch
 """
 from .autograd import Gradients, AbstractTensor
 
@@ -19,8 +25,12 @@ class Optimizer(object):
     def __init__(self, parameters) -> None:
         self.parameters = tuple(parameters)
         assert all(isinstance(p, AbstractTensor) for p in self.parameters)
+        self._flat_grad = None
 
     def zero_grad(self) -> None:
+        if self._flat_grad is not None:
+            self._flat_grad.fill(0)           # every p.grad is a view into this bucket
+            return
         for p in self.parameters:
             p.zero_grad()
 
@@ -48,7 +58,6 @@ class SGD(Optimizer):
 
 class Adam(Optimizer):
     """ ADAptive Moment estimation """
-
     belief = False
 
     def __init__(self, parameters, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
@@ -58,15 +67,43 @@ class Adam(Optimizer):
         self.t = 0
         self.m = [0] * len(self.parameters)
         self.v = [0] * len(self.parameters)
-        # fused: use the backend's one-kernel update when the tensor class offers `_fused_adam_step`
         # grad_scale: factor applied to every gradient first (1/world_size in data-parallel training)
-        # device_step (needs fused): the step counter behind the bias corrections lives in device memory, so the
-        # whole training step can be captured in a hipGraph and replayed (autograd/hip/graph.py)
         self.fused, self.grad_scale, self.device_step = fused, grad_scale, device_step
         self._step_counter = None
+        self._flat = None               # (flat_params, flat_m, flat_v, offsets) once use_flat_buckets() was called
+
+    def second_moment_input(self, grad, m):
+        return grad
+
+    def compute_delta(self, grad, i):
+        self.t += 1
+        self.m[i] = self.b1 * self.m[i] + (1 - self.b1) * grad
+        self.v[i] = self.b2 * self.v[i] + (1 - self.b2) * self.second_moment_input(grad, self.m[i])**2
+        m, v = self.m[i] / (1 - self.b1**self.t), self.v[i] / (1 - self.b2**self.t)
+        return -self.lr * m / (v**0.5 + self.eps)
+
+    def use_flat_buckets(self, flat_params, flat_grads, offsets) -> None:
+        """called by dist.DataParallel(flatten=True).attach(optimizer): parameter i is
+        flat_params[offsets[i]:offsets[i+1]] and its gradient the same slice of flat_grads"""
+        assert self.t == 0, "switch to flat buckets before the first step"
+        assert self.fused and self.device_step and hasattr(flat_params, "_fused_adam_multi_dev"), \
+            "flat buckets need fused=True, device_step=True and a backend with a multi-tensor kernel"
+        cls = flat_params.__class__
+        self._flat_grad = flat_grads
+        self._flat = (flat_params, cls.zeros(flat_params.shape, requires_grad=False),
+                      cls.zeros(flat_params.shape, requires_grad=False), tuple(int(o) for o in offsets))
+        self._step_counter = flat_params._new_step_counter(0)
 
     @Gradients.no_grad()
     def step(self) -> None:
+        n_params = len(self.parameters)
+        if self._flat is not None:
+            flat_p, flat_m, flat_v, offsets = self._flat
+            flat_p._fused_adam_multi_dev(self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2, self.eps,
+                                         self._step_counter, self.grad_scale, self.belief)
+            flat_p._advance_step_counter(self._step_counter)
+            self.t += n_params
+            return
         for i, p in enumerate(self.parameters):
             kernel = getattr(p, "_fused_adam_step", None) if self.fused else None
             if kernel is None:
@@ -79,9 +116,9 @@ class Adam(Optimizer):
                 self.v[i] = p.__class__.zeros(p.shape, requires_grad=False)
             if self.device_step:
                 if self._step_counter is None:
-                    self._step_counter = p._new_step_counter((self.t - 1) // len(self.parameters))
+                    self._step_counter = p._new_step_counter((self.t - 1) // n_params)
                 p._fused_adam_step_dev(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
-                                       self._step_counter, len(self.parameters), i + 1, self.grad_scale, self.belief)
+                                       self._step_counter, n_params, i + 1, self.grad_scale, self.belief)
             else:
                 kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
                        (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
@@ -91,16 +128,6 @@ class Adam(Optimizer):
     def on_graph_replay(self, n: int = 1) -> None:
         """keep the host-side step count in line after `n` replays of a captured step"""
         self.t += n * len(self.parameters)
-
-    def second_moment_input(self, grad, m):
-        return grad
-
-    def compute_delta(self, grad, i):
-        self.t += 1
-        self.m[i] = self.b1 * self.m[i] + (1 - self.b1) * grad
-        self.v[i] = self.b2 * self.v[i] + (1 - self.b2) * self.second_moment_input(grad, self.m[i])**2
-        m, v = self.m[i] / (1 - self.b1**self.t), self.v[i] / (1 - self.b2**self.t)
-        return -self.lr * m / (v**0.5 + self.eps)
 
 
 class AdaBelief(Adam):

@@ -1,0 +1,80 @@
+"""Fused forms on the HIP path against the unfused tape and the reference fixtures:
+nn.Linear as one op with the bias in the GEMM epilogue, loss.mse in one kernel, the multi-tensor
+optimizer over flat buckets.  All must reproduce the reference trajectory."""
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from lightgrad_amd import CpuTensor
+from conftest import load_golden
+import np_oracle as O
+from test_cpu_backend import MLP
+
+pytestmark = pytest.mark.gpu
+
+
+def test_linear_op_equals_three_op_form(hip):
+    rng = np.random.RandomState(0)
+    for (batch, d_in, d_out) in [(32, 48, 20), (1024, 784, 512), (1024, 512, 10), (7, 5, 3)]:
+        x, w, b = (rng.uniform(-1, 1, s).astype(np.float32) for s in [(batch, d_in), (d_out, d_in), (d_out,)])
+        g = rng.uniform(-1, 1, (batch, d_out)).astype(np.float32)
+        tx, tw, tb = hip.from_numpy(x), hip.from_numpy(w), hip.from_numpy(b)
+        y = tx.linear(tw, tb)
+        (y * hip.from_numpy(g, requires_grad=False)).backward(allow_fill=True)
+        ux, uw, ub = hip.from_numpy(x), hip.from_numpy(w), hip.from_numpy(b)
+        y2 = ux @ uw.T(1, 0) + ub
+        (y2 * hip.from_numpy(g, requires_grad=False)).backward(allow_fill=True)
+        np.testing.assert_allclose(y.numpy(), y2.numpy(), rtol=1e-6, atol=1e-6)
+        ref = x.astype(np.float64) @ w.T + b
+        np.testing.assert_allclose(y.numpy(), ref, rtol=1e-5, atol=1e-5)
+        for p, q in [(tx, ux), (tw, uw), (tb, ub)]:
+            np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=1e-5, atol=1e-5)
+        assert tw.grad.is_contiguous() and tw.grad.shape == w.shape
+        np.testing.assert_allclose(tb.grad.numpy(), g.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    # no bias, batched input
+    x3 = rng.uniform(-1, 1, (3, 5, 8)).astype(np.float32)
+    w3 = rng.uniform(-1, 1, (4, 8)).astype(np.float32)
+    np.testing.assert_allclose(hip.from_numpy(x3).linear(hip.from_numpy(w3)).numpy(), x3 @ w3.T, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_mse_equals_tape_expression(hip):
+    rng = np.random.RandomState(1)
+    for shape in [(8, 10), (1024, 10), (300, 700)]:
+        y, t = rng.uniform(-1, 1, shape).astype(np.float32), rng.uniform(0, 1, shape).astype(np.float32)
+        ty = hip.from_numpy(y)
+        l = light.loss.mse(ty, hip.from_numpy(t))
+        l.backward()
+        cy = CpuTensor.from_numpy(y)
+        lc = light.loss.mse(cy, CpuTensor.from_numpy(t))
+        lc.backward()
+        assert l.shape == ()
+        np.testing.assert_allclose(l.item(), lc.item(), rtol=1e-6)
+        np.testing.assert_array_equal(ty.grad.numpy(), cy.grad.numpy())          # err * 1.0: exact
+
+
+def test_flat_buckets_single_launch_update_reproduces_reference(hip):
+    from lightgrad_amd.dist import DataParallel, SingleProcess
+    g = load_golden("mlp_small_adabelief.npz")
+    d_in, d_hid, d_out, batch, steps, seed = (int(v) for v in g["config"])
+    model = MLP(d_in, d_hid, d_out)
+    model.load_parameters({n: g["w0/" + n] for n in O.PARAM_ORDER})
+    model.map_parameters(lambda p: p.hip())
+    dp = DataParallel(model.parameters(), SingleProcess(), flatten=True)
+    opt = dp.attach(light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=True, device_step=True, grad_scale=dp.grad_scale))
+    for (n, p) in model.named_parameters():                                     # same objects, new home
+        np.testing.assert_array_equal(p.numpy(), g["w0/" + n])
+        assert p.data is dp.flat_parameters.data
+    onehot = np.zeros((batch, d_out), np.float32)
+    onehot[np.arange(batch), g["labels"]] = 1
+    x, t = hip.from_numpy(g["x"]), hip.from_numpy(onehot)
+    losses = []
+    for _ in range(steps):
+        l = light.loss.mse(model(x), t)
+        opt.zero_grad()
+        l.backward()
+        dp.sync_gradients()
+        opt.step()
+        losses.append(l.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    assert opt.t == steps * 4

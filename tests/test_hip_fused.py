@@ -25,7 +25,7 @@ def test_linear_op_equals_three_op_form(hip):
         (y2 * hip.from_numpy(g, requires_grad=False)).backward(allow_fill=True)
         np.testing.assert_allclose(y.numpy(), y2.numpy(), rtol=1e-6, atol=1e-6)
         ref = x.astype(np.float64) @ w.T + b
-        np.testing.assert_allclose(y.numpy(), ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(y.numpy(), ref, rtol=1e-5, atol=1e-6 * d_in ** 0.5 * 4)
         for p, q in [(tx, ux), (tw, uw), (tb, ub)]:
             np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=1e-5, atol=1e-5)
         assert tw.grad.is_contiguous() and tw.grad.shape == w.shape

@@ -6,13 +6,18 @@
 
 namespace lg {
 
+// sum over the block (blockDim.x = 64 * NW); every thread returns the same value
+template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* lds) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) lds[wave] = v;
     __syncthreads();
-    return (lds[0] + lds[1]) + (lds[2] + lds[3]);     // every thread reads the same four partials
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += lds[w];
+    return s;
 }
 
 __global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ y, const float* __restrict__ t, float* __restrict__ err,
@@ -25,7 +30,7 @@ __global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ y, 
         err[i] = e;
         acc += e * e;
     }
-    const float s = block_sum(acc, lds);
+    const float s = block_sum<4>(acc, lds);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
@@ -34,21 +39,33 @@ __global__ void __launch_bounds__(256) mse_final(const float* __restrict__ parti
     __shared__ float lds[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
-    const float s = block_sum(acc, lds);
+    const float s = block_sum<4>(acc, lds);
     if (threadIdx.x == 0) loss[0] = (s * inv_n) * 0.5f;
 }
 
 // small inputs: a single block does both steps
-__global__ void __launch_bounds__(256) mse_single(const float* __restrict__ y, const float* __restrict__ t, float* __restrict__ err,
-                                                  float* __restrict__ loss, int64_t n, float inv_n) {
-    __shared__ float lds[4];
+__global__ void __launch_bounds__(1024) mse_single(const float* __restrict__ y, const float* __restrict__ t, float* __restrict__ err,
+                                                   float* __restrict__ loss, int64_t n, float inv_n, int vec) {
+    __shared__ float lds[16];
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    int64_t done = 0;
+    if (vec) {      // all three pointers 16-byte aligned
+        const int64_t nv = n / 4;
+        for (int64_t i = threadIdx.x; i < nv; i += 1024) {
+            const float4 a = reinterpret_cast<const float4*>(y)[i], b = reinterpret_cast<const float4*>(t)[i];
+            float4 e;
+            e.x = a.x + (-b.x); e.y = a.y + (-b.y); e.z = a.z + (-b.z); e.w = a.w + (-b.w);
+            reinterpret_cast<float4*>(err)[i] = e;
+            acc += (e.x * e.x + e.y * e.y) + (e.z * e.z + e.w * e.w);
+        }
+        done = nv * 4;
+    }
+    for (int64_t i = done + threadIdx.x; i < n; i += 1024) {
         const float e = y[i] + (-t[i]);
         err[i] = e;
         acc += e * e;
     }
-    const float s = block_sum(acc, lds);
+    const float s = block_sum<16>(acc, lds);
     if (threadIdx.x == 0) loss[0] = (s * inv_n) * 0.5f;
 }
 
@@ -63,7 +80,8 @@ extern "C" int lg_mse_f32(const float* y, const float* t, float* err, float* los
     hipStream_t s = rt().stream;
     const float inv_n = float(1.0 / double(n));      // python's `s.numel() / t.numel()` rounded once to fp32
     if (n <= 32768) {
-        hipLaunchKernelGGL(mse_single, dim3(1), dim3(256), 0, s, y, t, err, loss, n, inv_n);
+        hipLaunchKernelGGL(mse_single, dim3(1), dim3(1024), 0, s, y, t, err, loss, n, inv_n,
+                           int(aligned16(y) && aligned16(t) && aligned16(err)));
     } else {
         const unsigned blocks = stream_grid((n + 3) / 4);
         float* partial = nullptr;

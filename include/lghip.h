@@ -120,6 +120,7 @@ typedef enum {
     /* unary: out0 = f(a) */
     LG_EW_COPY = 0, LG_EW_NEG, LG_EW_EXP, LG_EW_LOG, LG_EW_RELU, LG_EW_SIGMOID,
     LG_EW_TANH, LG_EW_SIN, LG_EW_COS, LG_EW_SQRT,
+    LG_EW_GELU,          /* tanh-approximated gelu of examples/bert.py:12, same evaluation order */
     /* binary: out0 = f(a, b) */
     LG_EW_ADD = 32, LG_EW_SUB, LG_EW_MUL, LG_EW_DIV, LG_EW_POW,
     LG_EW_RELU_BWD,      /* a = saved input t, b = g :  g * (t >= 0)        (cpu/ops.py:229) */
@@ -131,6 +132,7 @@ typedef enum {
     LG_EW_EQ,            /* (a == b) ? 1 : 0 */
     LG_EW_GE,            /* (a >= b) ? 1 : 0 */
     LG_EW_BIAS_RELU,     /* a = x, b = bias         :  max(x + b, 0)  (fused Linear bias + relu) */
+    LG_EW_GELU_BWD,      /* a = x, b = g            :  g * gelu'(x) */
     /* ternary: out0 = f(a, b, c) */
     LG_EW_MAX_BWD = 64,  /* a = x, b = extremum, c = g : g * (x == b)      (cpu/ops.py:272) */
     LG_EW_FMA,           /* a * b + c (two roundings, like the tape's mul then add) */
@@ -221,6 +223,25 @@ int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg
  *   err[i] = y[i] + (-y_hat[i]);   loss[0] = (sum_i err[i]^2 * (1/n)) * 0.5
  * `err` is what mse.backward multiplies by the upstream gradient (loss.py:11-12). */
 int lg_mse_f32(const float* y, const float* y_hat, float* err, float* loss, int64_t n);
+
+/* ---- row-wise fused ops for the tiny-BERT path -------
+ * Dense fp32 [rows, cols] operands; one wavefront owns a row.
+ * softmax over the last axis = the composite of autograd/ops.py:62-66; backward dx = y * (g - sum(g*y)).
+ * layernorm = the composite of nn.py:109-124 for a 1-D normalised shape; saves xhat and rstd for the backward,
+ * which returns dx only (dw = sum_rows(g * xhat), db = sum_rows(g) are lg_ew + lg_reduce calls). */
+int lg_softmax_f32(const float* x, float* y, int64_t rows, int64_t cols);
+int lg_softmax_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols);
+int lg_layernorm_f32(const float* x, const float* w, const float* b, float* y, float* xhat, float* rstd,
+                     int64_t rows, int64_t cols, double eps);
+int lg_layernorm_bwd_f32(const float* g, const float* w, const float* xhat, const float* rstd, float* dx,
+                         int64_t rows, int64_t cols);
+/* embedding lookup out[i, :] = table[ids[i], :] (ids int32 or int64, negative ids wrap like numpy) and its
+ * gradient grad_table[ids[i], :] += grad_out[i, :] (float atomics: repeated ids ACCUMULATE; the reference's
+ * numpy `grad[idx] = g`, cpu/ops.py:245, keeps only the last one, and its BERT example drops the gradient). */
+int lg_gather_rows_f32(const float* table, const void* ids, int id_itemsize, float* out,
+                       int64_t n_ids, int64_t row_len, int64_t table_rows);
+int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, int id_itemsize, float* grad_table,
+                            int64_t n_ids, int64_t row_len, int64_t table_rows);
 
 /* library build info: "liblghip <version> gfx950 <build date>" */
 const char* lg_version(void);

@@ -14,9 +14,9 @@ LIB_PATH = os.path.join(_PKG_DIR, "liblghip.so")
 COMM_LIB_PATH = os.path.join(_PKG_DIR, "liblghip_comm.so")
 
 # lg_ew op ids (lghip.h: lg_ew_op_t)
-EW_COPY, EW_NEG, EW_EXP, EW_LOG, EW_RELU, EW_SIGMOID, EW_TANH, EW_SIN, EW_COS, EW_SQRT = range(10)
+EW_COPY, EW_NEG, EW_EXP, EW_LOG, EW_RELU, EW_SIGMOID, EW_TANH, EW_SIN, EW_COS, EW_SQRT, EW_GELU = range(11)
 (EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_POW, EW_RELU_BWD, EW_SIGMOID_BWD, EW_TANH_BWD, EW_LOG_BWD,
- EW_SIN_BWD, EW_COS_BWD, EW_EQ, EW_GE, EW_BIAS_RELU) = range(32, 46)
+ EW_SIN_BWD, EW_COS_BWD, EW_EQ, EW_GE, EW_BIAS_RELU, EW_GELU_BWD) = range(32, 47)
 EW_MAX_BWD, EW_FMA = 64, 65
 EW_MUL_BWD, EW_DIV_BWD, EW_POW_BWD = 96, 97, 98
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
@@ -73,6 +73,12 @@ PROTOTYPES = {
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_mse_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "lg_softmax_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),
+    "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
+    "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
 }
 
 COMM_PROTOTYPES = {

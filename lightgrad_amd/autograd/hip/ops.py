@@ -539,10 +539,15 @@ class getitem(Function):
     """ view + dense copy (opencl/ops.py:315-329); backward scatters into zeros (cpu/ops.py:242-246) """
     def forward(ctx, a, idx):
         ctx.save_for_backward(a._shape, idx)
+        if isinstance(idx, HipTensor):
+            # integer tensor index on the first axis = embedding lookup (examples/bert.py:19-21 does it on the CPU)
+            return _gather_rows(a, idx)
         return _idx_view(a, idx).copy()
 
     def backward(ctx, out_grad):
         shape, idx = ctx.get_saved_tensors()
+        if isinstance(idx, HipTensor):
+            return _scatter_add_rows(shape, idx, out_grad)      # repeated ids accumulate
         grad = HipTensor.zeros(shape, dtype=out_grad._dtype, requires_grad=False)
         grad[idx] = out_grad
         return grad
@@ -664,6 +669,103 @@ class linear(Function):
         if not has_bias:
             return dx, dw
         return dx, dw, _reduce(_l.RED_SUM, g2, (0,), False)
+
+
+gelu = HipTensor.register_op("gelu", _unary_op("gelu", _l.EW_GELU, _l.EW_GELU_BWD, False,
+                                               "tanh-approximated gelu of examples/bert.py:12 as one kernel (fwd) / one kernel (bwd)"))
+
+
+def _rows_view(t):
+    """dense (rows, cols) pointer view of a tensor whose last axis is the row"""
+    t = t.contiguous()
+    cols = t._shape[-1] if len(t._shape) else 1
+    return t, (t.numel() // cols if cols else 0), cols
+
+
+@HipTensor.register_op(overwrite=True)
+class softmax(Function):
+    """ row-wise fused softmax (composite: autograd/ops.py:62-66: exp(t - max) * (sum ** -1)); any axis is moved last """
+    def forward(ctx, t, axis=-1):
+        _require_f32(t)
+        nd = len(t._shape)
+        axis = axis % nd
+        perm = None
+        if axis != nd - 1:
+            perm = tuple(i for i in range(nd) if i != axis) + (axis,)
+            t = t.transpose(*perm)
+        x, rows, cols = _rows_view(t)
+        y = HipTensor.empty(x._shape)
+        _l.check(_l.lib().lg_softmax_f32(x.ptr, y.ptr, rows, cols))
+        ctx.save_for_backward(y, perm)
+        if perm is not None:
+            inv = [0] * nd
+            for i, j in enumerate(perm):
+                inv[j] = i
+            y = HipTensor(y.data, tuple(y._shape[i] for i in inv), tuple(y._strides[i] for i in inv), y._offset, y._dtype)
+        return y
+
+    def backward(ctx, out_grad):
+        y, perm = ctx.get_saved_tensors()
+        g = out_grad.transpose(*perm) if perm is not None else out_grad
+        g, rows, cols = _rows_view(g)
+        dx = HipTensor.empty(y._shape)
+        _l.check(_l.lib().lg_softmax_bwd_f32(y.ptr, g.ptr, dx.ptr, rows, cols))
+        if perm is not None:
+            inv = [0] * len(perm)
+            for i, j in enumerate(perm):
+                inv[j] = i
+            dx = dx.transpose(*inv)
+        return dx
+
+
+@HipTensor.register_op()
+class layer_norm(Function):
+    """ nn.LayerNorm over the last axis in one kernel (composite: nn.py:109-124); backward dx fused,
+    dw = sum_rows(g * xhat), db = sum_rows(g) """
+    def forward(ctx, x, weight, bias, eps=1e-5):
+        _require_f32(x, weight, bias)
+        assert len(weight._shape) == 1 and weight._shape == bias._shape == x._shape[-1:], \
+            "layer_norm fuses a 1-D normalised shape; got %s for input %s" % (weight._shape, x._shape)
+        xc, rows, cols = _rows_view(x)
+        w, b = weight.contiguous(), bias.contiguous()
+        y, xhat, rstd = HipTensor.empty(xc._shape), HipTensor.empty(xc._shape), HipTensor.empty((rows,))
+        _l.check(_l.lib().lg_layernorm_f32(xc.ptr, w.ptr, b.ptr, y.ptr, xhat.ptr, rstd.ptr, rows, cols, float(eps)))
+        ctx.save_for_backward(w, xhat, rstd, rows, cols)
+        return y
+
+    def backward(ctx, out_grad):
+        w, xhat, rstd, rows, cols = ctx.get_saved_tensors()
+        g = out_grad.contiguous()
+        dx = HipTensor.empty(xhat._shape)
+        _l.check(_l.lib().lg_layernorm_bwd_f32(g.ptr, w.ptr, xhat.ptr, rstd.ptr, dx.ptr, rows, cols))
+        g2 = HipTensor(g.data, (rows, cols), None, g._offset, g._dtype)
+        h2 = HipTensor(xhat.data, (rows, cols), None, xhat._offset, xhat._dtype)
+        dw = _reduce(_l.RED_SUM, _binary(_l.EW_MUL, g2, h2), (0,), False)
+        db = _reduce(_l.RED_SUM, g2, (0,), False)
+        return dx, dw, db
+
+
+def _gather_rows(table, ids):
+    """table[ids]: ids is an int32/int64 HipTensor indexing the first axis (embedding lookup)"""
+    _require_f32(table)
+    assert ids._dtype in (np.dtype(np.int32), np.dtype(np.int64)), "index tensor must be int32 or int64, got %s" % ids._dtype
+    table, ids = table.contiguous(), ids.contiguous()
+    row_len = 1
+    for s in table._shape[1:]:
+        row_len *= s
+    out = HipTensor.empty(ids._shape + table._shape[1:])
+    _l.check(_l.lib().lg_gather_rows_f32(table.ptr, ids.ptr, ids._dtype.itemsize, out.ptr, ids.numel(), row_len, table._shape[0]))
+    return out
+
+
+def _scatter_add_rows(shape, ids, out_grad):
+    grad = HipTensor.zeros(shape, requires_grad=False)
+    ids, g = ids.contiguous(), out_grad.contiguous()
+    row_len = 1
+    for s in shape[1:]:
+        row_len *= s
+    _l.check(_l.lib().lg_scatter_add_rows_f32(g.ptr, ids.ptr, ids._dtype.itemsize, grad.ptr, ids.numel(), row_len, shape[0]))
+    return grad
 
 
 def mse_forward(y, y_hat):

@@ -157,16 +157,28 @@ class AbstractTensor(metaclass=_TensorType):
             Gradients.enable()
 
     def zero_grad(self, traverse_graph: bool = False) -> None:
+        if not traverse_graph:
+            self._zero_own_grad()
+            return
+        # walk every ancestor ONCE (the reference recurses, tensor.py:127-131, which revisits shared sub-graphs
+        # and is exponential on residual networks; zeroing is idempotent, so a visited set changes nothing else)
+        seen, stack = {id(self)}, [self]
+        while stack:
+            t = stack.pop()
+            t._zero_own_grad()
+            if t._ctx is not None:
+                for p in t._ctx.parent_tensors:
+                    assert p is not t
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        stack.append(p)
+
+    def _zero_own_grad(self) -> None:
         if self._requires_grad:
             if self._grad is None or self._grad_shared:
                 self._grad, self._grad_shared = self.__class__.zeros(self.shape, requires_grad=False), False
             else:
                 self._grad.fill(0)
-        if traverse_graph and (self._ctx is not None):
-            parents = self._ctx.parent_tensors
-            assert all(t is not self for t in parents)
-            for t in parents:
-                t.zero_grad(traverse_graph=True)
 
     """ Registration of operations and backends """
 

@@ -34,6 +34,10 @@ LG_OP(OpTanh, 1, 1, out[0] = tanhf(in[0]);)
 LG_OP(OpSin, 1, 1, out[0] = sinf(in[0]);)
 LG_OP(OpCos, 1, 1, out[0] = cosf(in[0]);)
 LG_OP(OpSqrt, 1, 1, out[0] = sqrtf(in[0]);)
+// tanh-approximated gelu, evaluated in the order of the reference's expression (examples/bert.py:12):
+//   0.5 * x * (1.0 + (x * 0.7978845608 * (1.0 + 0.044715 * x * x)).tanh())
+__device__ __forceinline__ float gelu_inner(float x) { return (x * 0.7978845608f) * (1.0f + (0.044715f * x) * x); }
+LG_OP(OpGelu, 1, 1, const float x = in[0]; out[0] = (0.5f * x) * (1.0f + tanhf(gelu_inner(x)));)
 
 LG_OP(OpAdd, 2, 1, out[0] = in[0] + in[1];)
 LG_OP(OpSub, 2, 1, out[0] = in[0] - in[1];)
@@ -46,6 +50,10 @@ LG_OP(OpTanhBwd, 2, 1, out[0] = (1.0f - in[0] * in[0]) * in[1];)
 LG_OP(OpLogBwd, 2, 1, out[0] = (1.0f / in[0]) * in[1];)
 LG_OP(OpSinBwd, 2, 1, out[0] = cosf(in[0]) * in[1];)
 LG_OP(OpCosBwd, 2, 1, out[0] = -sinf(in[0]) * in[1];)
+// a = x, b = g: d/dx [0.5 x (1 + tanh u)] = 0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) u',  u' = 0.7978845608 (1 + 3*0.044715 x^2)
+LG_OP(OpGeluBwd, 2, 1, const float x = in[0]; const float th = tanhf(gelu_inner(x));
+      const float du = 0.7978845608f * (1.0f + 0.134145f * x * x);
+      out[0] = in[1] * (0.5f * (1.0f + th) + (0.5f * x) * (1.0f - th * th) * du);)
 LG_OP(OpEq, 2, 1, out[0] = in[0] == in[1] ? 1.0f : 0.0f;)
 LG_OP(OpGe, 2, 1, out[0] = in[0] >= in[1] ? 1.0f : 0.0f;)
 
@@ -349,8 +357,8 @@ extern "C" int lg_ew(int op, int ndim, const int64_t* shape,
     LG_ARG(out0 != nullptr, "lg_ew: out0 is NULL");
 
     int nin, nout;
-    if (op >= LG_EW_COPY && op <= LG_EW_SQRT) { nin = 1; nout = 1; }
-    else if (op >= LG_EW_ADD && op <= LG_EW_BIAS_RELU) { nin = 2; nout = 1; }
+    if (op >= LG_EW_COPY && op <= LG_EW_GELU) { nin = 1; nout = 1; }
+    else if (op >= LG_EW_ADD && op <= LG_EW_GELU_BWD) { nin = 2; nout = 1; }
     else if (op >= LG_EW_MAX_BWD && op <= LG_EW_FMA) { nin = 3; nout = 1; }
     else if (op == LG_EW_MUL_BWD || op == LG_EW_DIV_BWD) { nin = 3; nout = 2; }
     else if (op == LG_EW_POW_BWD) { nin = 4; nout = 2; }
@@ -390,7 +398,8 @@ extern "C" int lg_ew(int op, int ndim, const int64_t* shape,
 #define LG_CASE(ID, OP) case ID: rc = launch_ew<OP>(args, desc); break;
         LG_CASE(LG_EW_COPY, OpCopy) LG_CASE(LG_EW_NEG, OpNeg) LG_CASE(LG_EW_EXP, OpExp) LG_CASE(LG_EW_LOG, OpLog)
         LG_CASE(LG_EW_RELU, OpRelu) LG_CASE(LG_EW_SIGMOID, OpSigmoid) LG_CASE(LG_EW_TANH, OpTanh)
-        LG_CASE(LG_EW_SIN, OpSin) LG_CASE(LG_EW_COS, OpCos) LG_CASE(LG_EW_SQRT, OpSqrt)
+        LG_CASE(LG_EW_SIN, OpSin) LG_CASE(LG_EW_COS, OpCos) LG_CASE(LG_EW_SQRT, OpSqrt) LG_CASE(LG_EW_GELU, OpGelu)
+        LG_CASE(LG_EW_GELU_BWD, OpGeluBwd)
         LG_CASE(LG_EW_ADD, OpAdd) LG_CASE(LG_EW_SUB, OpSub) LG_CASE(LG_EW_MUL, OpMul) LG_CASE(LG_EW_DIV, OpDiv)
         LG_CASE(LG_EW_POW, OpPow) LG_CASE(LG_EW_RELU_BWD, OpReluBwd) LG_CASE(LG_EW_SIGMOID_BWD, OpSigmoidBwd)
         LG_CASE(LG_EW_TANH_BWD, OpTanhBwd) LG_CASE(LG_EW_LOG_BWD, OpLogBwd) LG_CASE(LG_EW_SIN_BWD, OpSinBwd)

@@ -1,0 +1,248 @@
+// Row-wise fused kernels for the tiny-BERT path: softmax, LayerNorm (forward and
+// backward) and embedding gather / scatter-add.  All HBM-bound: one pass over each row, the row lives in
+// registers of ONE wavefront (rows up to 64 * 32 = 2048 floats; the BERT rows are 128 wide) and is reduced with
+// wave64 shuffles - no LDS, no second read.  Longer rows take the same code with a strided loop that re-reads.
+//
+// Reference semantics (composites these replace):
+//   softmax   autograd/ops.py:62-66   exps = (t - max).exp(); exps / exps.sum()      ('/' = a * b**-1, ops.py:30-36)
+//   LayerNorm nn.py:109-124           D = x - mean; V = mean(D*D); D / (V + eps)**0.5 * weight + bias
+//   Embedding examples/bert.py:14-21  weight[ids]  (the reference round-trips through the CPU and drops the gradient)
+#include "common.h"
+
+namespace lg {
+
+constexpr int kRowRegs = 32;     // floats per lane held in registers: rows up to 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = (v > o || v != v) ? v : o;      // NaN propagates like np.max
+    }
+    return v;
+}
+
+// ---- softmax over the last axis --------------------------------------------------------------------
+// one wave per row; 4 rows per 256-thread block
+// REGS = floats per lane kept in registers (row length <= 64 * REGS); 0 = strided loops that re-read the row
+template <int REGS>
+__global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * cols;
+    float* yr = y + row * cols;
+    constexpr bool IN_REGS = REGS > 0;
+    float v[IN_REGS ? REGS : 1];
+    float m = -INFINITY;
+    if constexpr (IN_REGS) {
+#pragma unroll
+        for (int k = 0; k < REGS; ++k) {
+            const int64_t c = lane + 64 * k;
+            v[k] = c < cols ? xr[c] : -INFINITY;
+            m = (v[k] > m || v[k] != v[k]) ? v[k] : m;
+        }
+    } else {
+        for (int64_t c = lane; c < cols; c += 64) { const float t = xr[c]; m = (t > m || t != t) ? t : m; }
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    if constexpr (IN_REGS) {
+#pragma unroll
+        for (int k = 0; k < REGS; ++k) {
+            const int64_t c = lane + 64 * k;
+            v[k] = c < cols ? expf(v[k] + (-m)) : 0.f;
+            s += v[k];
+        }
+    } else {
+        for (int64_t c = lane; c < cols; c += 64) s += expf(xr[c] + (-m));
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    if constexpr (IN_REGS) {
+#pragma unroll
+        for (int k = 0; k < REGS; ++k) {
+            const int64_t c = lane + 64 * k;
+            if (c < cols) yr[c] = v[k] * inv;
+        }
+    } else {
+        for (int64_t c = lane; c < cols; c += 64) yr[c] = expf(xr[c] + (-m)) * inv;
+    }
+}
+
+// dx = y * (g - sum(g * y))
+__global__ void __launch_bounds__(256) softmax_bwd(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ dx,
+                                                   int64_t rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* yr = y + row * cols;
+    const float* gr = g + row * cols;
+    float* dr = dx + row * cols;
+    float dot = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) dot += gr[c] * yr[c];
+    dot = wave_sum(dot);
+    for (int64_t c = lane; c < cols; c += 64) dr[c] = yr[c] * (gr[c] - dot);
+}
+
+// ---- LayerNorm over the last axis ---------------------------------------------------------------------
+// y = ((x - mean) * rstd) * w + b ; saves xhat = (x - mean) * rstd and rstd for the backward
+__global__ void __launch_bounds__(256) layernorm_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ rstd,
+                                                     int64_t rows, int64_t cols, float eps, float inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * cols;
+    float s = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) s += xr[c];
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float var = wave_sum(q) * inv_n;
+    const float r = 1.0f / sqrtf(var + eps);
+    if (lane == 0) rstd[row] = r;
+    for (int64_t c = lane; c < cols; c += 64) {
+        const float h = (xr[c] - mean) * r;
+        xhat[row * cols + c] = h;
+        y[row * cols + c] = h * w[c] + b[c];
+    }
+}
+
+// dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = g * w
+__global__ void __launch_bounds__(256) layernorm_bwd(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx, int64_t rows, int64_t cols,
+                                                     float inv_n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* gr = g + row * cols;
+    const float* hr = xhat + row * cols;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) {
+        const float gh = gr[c] * w[c];
+        s1 += gh;
+        s2 += gh * hr[c];
+    }
+    s1 = wave_sum(s1) * inv_n;
+    s2 = wave_sum(s2) * inv_n;
+    const float r = rstd[row];
+    for (int64_t c = lane; c < cols; c += 64) dx[row * cols + c] = r * (gr[c] * w[c] - s1 - hr[c] * s2);
+}
+
+// ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
+template <typename IdT>
+__global__ void __launch_bounds__(256) gather_rows(const float* __restrict__ table, const IdT* __restrict__ ids, float* __restrict__ out,
+                                                   int64_t n_ids, int64_t row_len, int64_t table_rows) {
+    const int64_t total = n_ids * row_len;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / row_len, c = e - i * row_len;
+        int64_t r = int64_t(ids[i]);
+        if (r < 0) r += table_rows;                               // numpy-style negative index
+        out[e] = (r >= 0 && r < table_rows) ? table[r * row_len + c] : __builtin_nanf("");   // host validates; NaN marks a bad id
+    }
+}
+
+template <typename IdT>
+__global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
+                                                        float* __restrict__ grad_table, int64_t n_ids, int64_t row_len, int64_t table_rows) {
+    const int64_t total = n_ids * row_len;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / row_len, c = e - i * row_len;
+        int64_t r = int64_t(ids[i]);
+        if (r < 0) r += table_rows;
+        if (r >= 0 && r < table_rows) atomicAdd(grad_table + r * row_len + c, grad_out[e]);   // global_atomic_add_f32, agent scope
+    }
+}
+
+}  // namespace lg
+
+using namespace lg;
+
+extern "C" int lg_softmax_f32(const float* x, float* y, int64_t rows, int64_t cols) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_softmax_f32: bad shape (%lld, %lld)", (long long)rows, (long long)cols);
+    if (rows == 0) return LG_OK;
+    LG_ARG(x && y, "lg_softmax_f32: NULL pointer");
+    const unsigned blocks = unsigned((rows + 3) / 4);
+    hipStream_t s = rt().stream;
+    if (cols <= 128)       hipLaunchKernelGGL(softmax_fwd<2>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
+    else if (cols <= 512)  hipLaunchKernelGGL(softmax_fwd<8>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
+    else if (cols <= 2048) hipLaunchKernelGGL(softmax_fwd<kRowRegs>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
+    else                   hipLaunchKernelGGL(softmax_fwd<0>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_softmax_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_softmax_bwd_f32: bad shape");
+    if (rows == 0) return LG_OK;
+    LG_ARG(y && g && dx, "lg_softmax_bwd_f32: NULL pointer");
+    hipLaunchKernelGGL(softmax_bwd, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, rt().stream, y, g, dx, rows, cols);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_layernorm_f32(const float* x, const float* w, const float* b, float* y, float* xhat, float* rstd,
+                                int64_t rows, int64_t cols, double eps) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_layernorm_f32: bad shape");
+    if (rows == 0) return LG_OK;
+    LG_ARG(x && w && b && y && xhat && rstd, "lg_layernorm_f32: NULL pointer");
+    hipLaunchKernelGGL(layernorm_fwd, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, rt().stream, x, w, b, y, xhat, rstd, rows, cols,
+                       float(eps), float(1.0 / double(cols)));
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_layernorm_bwd_f32(const float* g, const float* w, const float* xhat, const float* rstd, float* dx,
+                                    int64_t rows, int64_t cols) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_layernorm_bwd_f32: bad shape");
+    if (rows == 0) return LG_OK;
+    LG_ARG(g && w && xhat && rstd && dx, "lg_layernorm_bwd_f32: NULL pointer");
+    hipLaunchKernelGGL(layernorm_bwd, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, rt().stream, g, w, xhat, rstd, dx, rows, cols,
+                       float(1.0 / double(cols)));
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_gather_rows_f32(const float* table, const void* ids, int id_itemsize, float* out, int64_t n_ids, int64_t row_len,
+                                  int64_t table_rows) {
+    LG_REQUIRE_INIT();
+    LG_ARG(id_itemsize == 4 || id_itemsize == 8, "lg_gather_rows_f32: ids must be int32 or int64");
+    LG_ARG(n_ids >= 0 && row_len >= 0 && table_rows >= 0, "lg_gather_rows_f32: bad shape");
+    if (n_ids == 0 || row_len == 0) return LG_OK;
+    LG_ARG(table && ids && out, "lg_gather_rows_f32: NULL pointer");
+    const unsigned grid = stream_grid(n_ids * row_len);
+    if (id_itemsize == 4)
+        hipLaunchKernelGGL(gather_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int32_t*>(ids), out, n_ids, row_len, table_rows);
+    else
+        hipLaunchKernelGGL(gather_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int64_t*>(ids), out, n_ids, row_len, table_rows);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, int id_itemsize, float* grad_table, int64_t n_ids,
+                                       int64_t row_len, int64_t table_rows) {
+    LG_REQUIRE_INIT();
+    LG_ARG(id_itemsize == 4 || id_itemsize == 8, "lg_scatter_add_rows_f32: ids must be int32 or int64");
+    LG_ARG(n_ids >= 0 && row_len >= 0 && table_rows >= 0, "lg_scatter_add_rows_f32: bad shape");
+    if (n_ids == 0 || row_len == 0) return LG_OK;
+    LG_ARG(grad_out && ids && grad_table, "lg_scatter_add_rows_f32: NULL pointer");
+    const unsigned grid = stream_grid(n_ids * row_len);
+    if (id_itemsize == 4)
+        hipLaunchKernelGGL(scatter_add_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int32_t*>(ids), grad_table, n_ids, row_len, table_rows);
+    else
+        hipLaunchKernelGGL(scatter_add_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int64_t*>(ids), grad_table, n_ids, row_len, table_rows);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

@@ -121,6 +121,9 @@ class LayerNorm(Module):
     def forward(self, x):
         assert x.shape[-len(self.shape):] == self.shape, \
             "Shape mismatch in layer norm! (%s <-> %s)" % (x.shape, self.shape)
+        if len(self.shape) == 1 and hasattr(x, "layer_norm"):
+            # optional backend op: the composite below over the last axis as one kernel (HipTensor)
+            return x.layer_norm(self.weight, self.bias, eps=self.eps)
         axes = tuple(range(len(x.shape) - len(self.shape), len(x.shape)))
         D = x - x.mean(axis=axes, keepdims=True)
         V = (D * D).mean(axis=axes, keepdims=True)

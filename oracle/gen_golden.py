@@ -149,6 +149,32 @@ def main():
     np.savez_compressed(os.path.join(OUT, "mlp_small_adam.npz"), **mlp_traj(20, 16, 10, 8, 12, "adam", 8, True))
     np.savez_compressed(os.path.join(OUT, "mlp_small_sgd.npz"), **mlp_traj(20, 16, 10, 8, 12, "sgd", 9, True))
     np.savez_compressed(os.path.join(OUT, "mlp_full_adabelief.npz"), **mlp_traj(784, 512, 10, 1024, 5, "adabelief", 0, False))
+    # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
+    # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
+    # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.
+    # Only the forward exists in the reference (its backward fails on three counts).
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_bert", os.path.join(REF, "examples", "bert.py"))
+    ref_bert = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_bert)
+    ref_bert.Embedding.forward = lambda self, ids: self.weight.cpu()[ids.cpu()]
+    tiny = dict(hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=30522,
+                max_position_embeddings=512, type_vocab_size=2, attention_probs_dropout_prob=0.0, hidden_dropout_prob=0.0)
+    np.random.seed(42)
+    model = ref_bert.BertForMaskedLM(**tiny)
+    ids = np.random.randint(0, tiny["vocab_size"], size=(2, 128)).astype(np.int32)
+    # the reference reshapes the mask to (1, 1, *mask.shape) (bert.py:82), which only broadcasts for batch 1
+    mask = np.ones((1, 128), dtype=np.float32)
+    mask[0, 100:] = 0
+    with light.no_grad():
+        logits = model(T.from_numpy(ids)).numpy()
+        logits_masked = model(T.from_numpy(ids[:1]), attention_mask=T.from_numpy(mask)).numpy()
+    wsum = {n: float(np.abs(p.numpy().astype(np.float64)).sum()) for n, p in model.named_parameters()}
+    np.savez_compressed(os.path.join(OUT, "bert_tiny_forward.npz"), ids=ids, mask=mask,
+                        logits_sample=logits[:, :, ::509].copy(), logits_masked_sample=logits_masked[:, ::8, ::509].copy(),
+                        logits_digest=np.asarray([logits.astype(np.float64).sum(), np.abs(logits).astype(np.float64).sum()]),
+                        argmax=logits.argmax(-1).astype(np.int64),
+                        param_names=np.asarray(sorted(wsum)), param_abs_sums=np.asarray([wsum[k] for k in sorted(wsum)]))
     print("fixtures written to", OUT)
 
 

@@ -1,0 +1,120 @@
+"""tiny-BERT and its row-wise fused ops on the HIP path: forward against the reference fixture, forward and
+backward against this repo's CPU backend (which test_bert_cpu.py pins to the reference / to numerical
+derivatives), fused softmax / LayerNorm / gelu / embedding against their composite definitions."""
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from lightgrad_amd import CpuTensor
+from common import check_gradients
+from conftest import load_golden
+from test_bert_cpu import bert, build_tiny, small_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_matches_reference_fixture(hip):
+    g = load_golden("bert_tiny_forward.npz")
+    model = build_tiny().map_parameters(lambda p: p.hip())
+    with light.no_grad():
+        logits = model(hip.from_numpy(g["ids"], requires_grad=False)).numpy()
+        masked = model(hip.from_numpy(g["ids"][:1], requires_grad=False),
+                       attention_mask=hip.from_numpy(g["mask"], requires_grad=False)).numpy()
+    np.testing.assert_allclose(logits[:, :, ::509], g["logits_sample"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(masked[:, ::8, ::509], g["logits_masked_sample"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.abs(logits).astype(np.float64).sum(), g["logits_digest"][1], rtol=1e-5)
+    assert (logits.argmax(-1) == g["argmax"]).mean() > 0.995
+
+
+def test_forward_backward_matches_cpu_backend(hip):
+    """full tiny config, batch 2: every parameter gradient of a scalar objective, HIP vs CPU"""
+    g = load_golden("bert_tiny_forward.npz")
+    cpu_model = build_tiny()
+    hip_model = build_tiny().map_parameters(lambda p: p.hip())
+    rng = np.random.RandomState(0)
+    w = rng.uniform(-1, 1, (2, 128, 30522)).astype(np.float32)
+    for model, T in ((cpu_model, CpuTensor), (hip_model, hip)):
+        logits = model(T.from_numpy(g["ids"], requires_grad=False))
+        (logits * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    for (n, p), (_, q) in zip(cpu_model.named_parameters(), hip_model.named_parameters()):
+        ref, got = p.grad.numpy(), q.grad.numpy()
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * scale, err_msg=n)
+
+
+def test_small_model_gradcheck(hip):
+    model = small_model().map_parameters(lambda p: p.hip())
+    ids = hip.from_numpy(np.array([[1, 4, 4, 7]], dtype=np.int32), requires_grad=False)
+    dense = model.bert.encoder.layer[0].output.dense
+
+    def f(w):
+        dense.weight = w
+        return model(ids)[0, :, ::3]
+    from lightgrad_amd.autograd.utils.gradcheck import assert_gradcheck
+    assert_gradcheck(f, hip.from_numpy(dense.weight.numpy()), eps=1e-2, atol=3e-3, rtol=3e-2)
+
+
+def composite_softmax(t, axis=-1):
+    e = (t - t.max(axis=axis, keepdims=True)).exp()
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+@pytest.mark.parametrize("shape,axis", [((7, 128), -1), ((2, 2, 128, 128), -1), ((5, 33), -1), ((6, 10, 12), 1), ((3, 700), -1), ((2, 2500), -1)])
+def test_fused_softmax(hip, shape, axis):
+    rng = np.random.RandomState(1)
+    x, w = rng.uniform(-3, 3, shape).astype(np.float32), rng.uniform(-1, 1, shape).astype(np.float32)
+    tx, ux = hip.from_numpy(x), hip.from_numpy(x)
+    y = tx.softmax(axis=axis)
+    (y * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    y2 = composite_softmax(ux, axis)
+    (y2 * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_allclose(y.numpy(), y2.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(y.numpy().sum(axis=axis), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(tx.grad.numpy(), ux.grad.numpy(), rtol=1e-4, atol=1e-6)
+    cy = CpuTensor.from_numpy(x).softmax(axis=axis).numpy()
+    np.testing.assert_allclose(y.numpy(), cy, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(4, 128), (2, 128, 128), (3, 5, 40), (9, 1000)])
+def test_fused_layernorm(hip, shape):
+    import lightgrad_amd.nn as nn
+    rng = np.random.RandomState(2)
+    x, w = rng.uniform(-2, 2, shape).astype(np.float32), rng.uniform(-1, 1, shape).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, shape[-1:]).astype(np.float32), rng.uniform(-1, 1, shape[-1:]).astype(np.float32)
+    ln_h, ln_c = nn.LayerNorm(shape[-1]), nn.LayerNorm(shape[-1])
+    ln_h.load_parameters({"weight": gamma, "bias": beta})
+    ln_c.load_parameters({"weight": gamma, "bias": beta})
+    ln_h.map_parameters(lambda p: p.hip())
+    tx, cx = hip.from_numpy(x), CpuTensor.from_numpy(x)
+    yh, yc = ln_h(tx), ln_c(cx)                                  # fused kernel vs the composite on the CPU backend
+    (yh * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    (yc * CpuTensor.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_allclose(yh.numpy(), yc.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(tx.grad.numpy(), cx.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ln_h.weight.grad.numpy(), ln_c.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ln_h.bias.grad.numpy(), ln_c.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_fused_gelu_and_gradcheck(hip):
+    rng = np.random.RandomState(3)
+    x = rng.uniform(-4, 4, (64, 130)).astype(np.float32)
+    comp = lambda t: 0.5 * t * (1.0 + (t * 0.7978845608 * (1.0 + 0.044715 * t * t)).tanh())   # noqa: E731
+    np.testing.assert_allclose(hip.from_numpy(x).gelu().numpy(), comp(CpuTensor.from_numpy(x)).numpy(), rtol=1e-5, atol=1e-6)
+    np.random.seed(4)
+    check_gradients(hip, "gelu", shapes=[(6, 6)], lowhigh=(-3, 3), tol=2e-3)
+    check_gradients(hip, lambda t: t.softmax(axis=-1), shapes=[(4, 7)], tol=2e-3)
+
+
+def test_embedding_gather_and_scatter_add(hip):
+    rng = np.random.RandomState(5)
+    table = rng.uniform(-1, 1, (50, 12)).astype(np.float32)
+    for dtype in (np.int32, np.int64):
+        ids = rng.randint(0, 50, (3, 9)).astype(dtype)
+        ids[0, :4] = 7                                             # repeated id: gradient must accumulate
+        ids[2, 0] = -1                                             # numpy-style negative index
+        w = rng.uniform(-1, 1, (3, 9, 12)).astype(np.float32)
+        tt, ct = hip.from_numpy(table), CpuTensor.from_numpy(table)
+        out = tt[hip.from_numpy(ids, requires_grad=False)]
+        np.testing.assert_array_equal(out.numpy(), table[ids])
+        (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        (ct[CpuTensor.from_numpy(ids, requires_grad=False)] * CpuTensor.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        np.testing.assert_allclose(tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)

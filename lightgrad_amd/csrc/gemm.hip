@@ -21,6 +21,7 @@
 // Reference semantics: `dot` = numpy matmul (cpu/ops.py:107-116); the tiled OpenCL kernel with its
 // pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
 #include "common.h"
+#include <cstdlib>
 
 namespace lg {
 
@@ -398,7 +399,25 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     } else if (M <= 32) {
         rc = launch_config<32, 64, 32, 1, 2>(g, akc, bkc, va, vb, batch);
     } else if (nblocks(128, 128) >= 384 || (M >= 2048 && N >= 2048)) {
-        rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch);
+        // Large problems: 256x256 tiles (16 waves, one workgroup per CU, measured 132-141 TFLOP/s at 4096^3) or
+        // 128x128 tiles (4 waves, two workgroups per CU, 108-124 TFLOP/s).  Pick by modelled time =
+        // rounds over the chip x tile area x workgroups per CU / efficiency, which accounts for edge padding and
+        // for the last, partly filled round.  LG_GEMM_TILE forces a variant (tools/gemm_bench.py).
+        static const char* tile_env = getenv("LG_GEMM_TILE");
+        int tile = tile_env ? atoi(tile_env) : -1;
+        if (tile < 0) {
+            const int64_t cus = rt().compute_units > 0 ? rt().compute_units : 256;
+            auto cost = [&](int64_t bm, int64_t bn, int64_t per_cu, double eff) {
+                const int64_t rounds = (nblocks(bm, bn) + cus * per_cu - 1) / (cus * per_cu);
+                return double(rounds) * double(bm * bn * per_cu) / eff;
+            };
+            tile = cost(256, 256, 1, 0.87) <= cost(128, 128, 2, 0.78) ? 2 : 0;
+        }
+        switch (tile) {
+            case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves, 64x64 per wave
+            case 2:  rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break;   // 16 waves, 64x64 per wave
+            default: rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
+        }
     } else {
         rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     }

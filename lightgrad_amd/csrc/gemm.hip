@@ -40,6 +40,7 @@ struct GemmArgs {
     const float* bias;      // optional [N]: added to every row of the product (nn.Linear's `+ b`, nn.py:96)
     // split-K: slice s of k_slices handles k in [s*k_per_slice, min(K, (s+1)*k_per_slice)) and writes its partial
     // product to W + (batch*k_slices + s)*M*N (dense, ld = N); splitk_combine sums the slices in a fixed order
+    int     group_m;        // tile rows walked before moving to the next tile column
     int     k_slices;
     int64_t k_per_slice;    // multiple of BK
     float*  W;
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     // grouped order: consecutive ids walk GROUP_M tile rows before moving to the next tile column, so the
     // ~64 workgroups resident on one XCD at a time cover a near-square patch of C and share both their
     // A row-panels and their B column-panels in that XCD's 4 MiB L2
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = g.group_m;
     const int gspan = GROUP_M * g.tiles_n;
     const int first_m = (t / gspan) * GROUP_M;
     const int gsize = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
@@ -381,6 +382,9 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.accumulate = accumulate;
     g.bias = bias;
+    static const char* group_env = getenv("LG_GEMM_GROUP");
+    g.group_m = group_env ? atoi(group_env) : 8;
+    if (g.group_m < 1) g.group_m = 1;
 
     const bool akc = !transA;   // A[m*lda + k]: k is the contiguous index
     const bool bkc = transB != 0;   // B[n*ldb + k]

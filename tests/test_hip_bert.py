@@ -37,6 +37,10 @@ def test_forward_backward_matches_cpu_backend(hip):
         (logits * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
     for (n, p), (_, q) in zip(cpu_model.named_parameters(), hip_model.named_parameters()):
         ref, got = p.grad.numpy().astype(np.float64), q.grad.numpy().astype(np.float64)
+        if ".key.bias" in n:
+            # mathematically zero (softmax is invariant to a per-query constant): both sides are rounding noise
+            assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6, (n, np.abs(got).max(), np.abs(ref).max())
+            continue
         rel = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300)
         # query/key gradients of a randomly initialised model are ~1e-8: pure cancellation through an almost uniform
         # softmax, so fp32 summation order shows up at the 1e-3 level; everything else agrees to ~1e-5

@@ -208,10 +208,18 @@ def main():
     for tag, (ta, tb) in {"NN": (0, 0), "NT": (0, 1), "TN": (1, 0)}.items():
         gemm_ms[tag] = time_launches(lambda: L.check(lib.lg_gemm_f32(ta, tb, n, n, n, a.ptr, n, 0, b.ptr, n, 0, c.ptr, n, 0, 1, 0)), 10)
     gemm_tf = {k: 2 * n ** 3 / (v * 1e-3) / 1e12 for k, v in gemm_ms.items()}
-    roofline = {"kernel": "sgemm_mfma<128,128,32> NN 4096^3", "bound": "mfma", "achieved": round(gemm_tf["NN"], 2),
-                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tf["NN"] / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(gemm_ms["NN"], 4),
-                "algorithmic_flop_per_launch": 2 * n ** 3}
+    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (profiles/r1/pmc_traffic.json; separate runs,
+    # corrected as MI355X_MICROARCH.md prescribes) - cannot be collected from inside this process
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get("sgemm_mfma_256x256_NN_4096", {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    roofline = {"kernel": "sgemm_mfma<256,256,32,4,4> NN 4096^3 (forward GEMM of the matmul workload)", "bound": "mfma",
+                "achieved": round(gemm_tf["NN"], 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(gemm_tf["NN"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(gemm_ms["NN"], 4), "algorithmic_flop_per_launch": 2 * n ** 3}
     # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache)
     big = (16384, 8192)
     nbig = big[0] * big[1]
@@ -242,6 +250,35 @@ def main():
     for v in hbm.values():
         v["frac_of_8TBs"] = round(v["GB/s"] / HBM_PEAK_GBS, 3)
     del p, q, r
+
+    # ------------------------------------------------------------------ tiny-BERT forward + backward (BASELINE config #5)
+    bert_ms = None
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bert_example", os.path.join(ROOT, "examples", "bert.py"))
+        bert = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bert)
+        np.random.seed(0)
+        bmodel = bert.BertForMaskedLM(**bert.TINY).map_parameters(lambda t: t.hip())
+        ids = HipTensor.from_numpy(np.random.randint(0, bert.TINY["vocab_size"], (8, 128)).astype(np.int32), requires_grad=False)
+
+        def bert_iter():
+            logits = bmodel(ids)
+            loss = (logits * logits).mean()
+            for prm in bmodel.parameters():
+                prm.zero_grad()
+            loss.backward()
+        for _ in range(3):
+            bert_iter()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            bert_iter()
+        fence()
+        bert_ms = 1e3 * wall_max(time.perf_counter() - t0) / 10
+        del bmodel
+    except Exception as e:            # the BERT row is "next" scope: never let it take the headline numbers down
+        bert_ms = "failed: %r" % (e,)
 
     # ------------------------------------------------------------------ CPU baseline (oracle, host cores)
     cpu_baseline = None
@@ -286,6 +323,8 @@ def main():
                           "ms_per_iter": round(1e3 * mm_elapsed / args.matmul_iters, 4), "iters": args.matmul_iters,
                           "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
                           "scaling": "replicas", "gemm_kernel_tflops": {k: round(v, 2) for k, v in gemm_tf.items()}},
+            "tiny_bert_fwd_bwd": {"ms_per_iter": bert_ms if isinstance(bert_ms, str) else round(bert_ms, 3), "batch": 8, "seq_len": 128,
+                                  "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522", "dispatch": "eager python tape"},
             "roofline": roofline,
             "roofline_hbm": hbm,
             "cpu_baseline": cpu_baseline,

@@ -119,7 +119,9 @@ class RcclCommunicator(Communicator):
         self._L = L
         self._lib = L.comm_lib()
         if id_path is None:
-            tag = "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"))
+            # all ranks of one launch are children of the same launcher process (torch.distributed.run agent):
+            # its pid makes the rendezvous file unique per launch, so a stale file of a crashed run is never read
+            tag = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.getppid())
             id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lightgrad_rccl_%s.id" % tag)
         self._id_path = id_path
 

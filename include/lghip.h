@@ -162,6 +162,12 @@ int lg_reduce(int op, int ndim, const int64_t* shape,
               const void* in, const int64_t* in_strides,
               uint32_t axis_mask, void* out);
 
+/* out (+)= reduction: with accumulate != 0 (sums only) the result is ADDED to `out`, so a bias gradient
+ * can be accumulated straight into its gradient buffer (tensor.py:118 `grad += g` without the extra pass). */
+int lg_reduce_acc(int op, int ndim, const int64_t* shape,
+                  const void* in, const int64_t* in_strides,
+                  uint32_t axis_mask, void* out, int accumulate);
+
 /* ---- SGEMM on MFMA ---------------------------------------------------------
  * C[b] (M x N, row-major, leading dimension ldc) (+)= op(A[b]) @ op(B[b]), fp32
  * in/out, fp32 accumulate on v_mfma_f32_32x32x2_f32.

@@ -83,7 +83,10 @@ class Function(object, metaclass=_FunctionType):
         for t, g in zip(self._parents, in_grads):
             if not (isinstance(t, AbstractTensor) and t.requires_grad):
                 continue
-            assert g is not None
+            if g is None:
+                # extension of the reference protocol (func.py:47 asserts non-None): a backward may add a gradient
+                # straight into `t._grad_accumulator()` (e.g. a GEMM with beta = 1) and report None for that parent
+                continue
             if g.shape != t.shape:
                 g = _unbroadcast(g, t.shape)
             assert g.shape == t.shape

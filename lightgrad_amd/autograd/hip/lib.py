@@ -61,6 +61,7 @@ PROTOTYPES = {
     "lg_ew": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P,
                       c_void_p, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_float]),
     "lg_reduce": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p]),
+    "lg_reduce_acc": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p, c_int]),
     "lg_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,

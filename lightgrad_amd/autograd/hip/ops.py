@@ -285,7 +285,7 @@ def _collapse_batch(shape, strides):
     return n, st
 
 
-def _gemm(a, b, out_colmajor=False, bias=None):
+def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None):
     """a (..., M, K) @ b (..., K, N) [+ bias (N,)] -> (..., M, N) on the MFMA SGEMM kernel.
 
     Operands are consumed in place whenever one of their last two dims has stride 1
@@ -322,7 +322,12 @@ def _gemm(a, b, out_colmajor=False, bias=None):
     for s in batch_shape:
         nb *= s
     out_shape = batch_shape + (M, N)
-    if out_colmajor:
+    if accumulate_into is not None:
+        # C += A @ B straight into an existing dense buffer (a parameter's gradient): no temporary, no add pass
+        assert not out_colmajor and bias is None and not batch_shape
+        assert accumulate_into._shape == out_shape and accumulate_into.is_contiguous() and accumulate_into._dtype == _F32
+        out = accumulate_into
+    elif out_colmajor:
         out = HipTensor.empty(batch_shape + (N, M))
     else:
         out = HipTensor.empty(out_shape)
@@ -350,7 +355,7 @@ def _gemm(a, b, out_colmajor=False, bias=None):
                                    pb, mb.ld, strb, pa, ma.ld, stra, po, M, stro, count, 0))
         else:
             _l.check(L.lg_gemm_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
-                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, 0))
+                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, 1 if accumulate_into is not None else 0))
 
     if nb > 0 and M > 0 and N > 0:
         ca, cb = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb)
@@ -583,6 +588,17 @@ def _norm_axes(nd, axis):
     return axes
 
 
+def _reduce_into(acc, x, axes):
+    """acc += x.sum(axes): the reduction's final pass adds into an existing dense buffer (lg_reduce_acc)"""
+    _require_f32(x, acc)
+    mask = 0
+    for a in axes:
+        mask |= 1 << a
+    kept = tuple(s for i, s in enumerate(x._shape) if i not in axes)
+    assert acc._shape == kept and acc.is_contiguous()
+    _l.check(_l.lib().lg_reduce_acc(_l.RED_SUM, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, acc.ptr, 1))
+
+
 def _reduce(op, x, axes, keepdims):
     _require_f32(x)
     mask = 0
@@ -661,14 +677,35 @@ class linear(Function):
 
     def backward(ctx, out_grad):
         x, weight, has_bias = ctx.get_saved_tensors()
+        bias = ctx._parents[2] if has_bias else None
         out_f = weight._shape[0]
         g2 = out_grad.reshape(-1, out_f)
         x2 = x.reshape(-1, x._shape[-1])
-        dw = _gemm(_swap_last(g2), x2) if weight.requires_grad else None
-        dx = _gemm(g2, weight).reshape(*x._shape) if x.requires_grad else None
+        # leaf operands that already own a gradient buffer (parameters after zero_grad, a re-used input) get their
+        # gradient ADDED in place by the producing kernel (GEMM with beta = 1 / reduction with accumulate) and None
+        # is reported for them - tensor.py:118's `grad += g` without the temporary and the extra pass
+        dw = dx = db = None
+        if weight.requires_grad:
+            acc = weight._grad_accumulator()
+            if acc is not None and acc.is_contiguous():
+                _gemm(_swap_last(g2), x2, accumulate_into=acc)
+            else:
+                dw = _gemm(_swap_last(g2), x2)
+        if x.requires_grad:
+            acc = x._grad_accumulator()
+            if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
+                _gemm(g2, weight, accumulate_into=acc)
+            else:
+                dx = _gemm(g2, weight).reshape(*x._shape)
         if not has_bias:
             return dx, dw
-        return dx, dw, _reduce(_l.RED_SUM, g2, (0,), False)
+        if bias.requires_grad:
+            acc = bias._grad_accumulator()
+            if acc is not None and acc.is_contiguous():
+                _reduce_into(acc, g2, (0,))
+            else:
+                db = _reduce(_l.RED_SUM, g2, (0,), False)
+        return dx, dw, db
 
 
 gelu = HipTensor.register_op("gelu", _unary_op("gelu", _l.EW_GELU, _l.EW_GELU_BWD, False,

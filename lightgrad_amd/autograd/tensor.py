@@ -156,6 +156,14 @@ class AbstractTensor(metaclass=_TensorType):
         finally:
             Gradients.enable()
 
+    def _grad_accumulator(self):
+        """The gradient buffer a backward op may add into directly, or None.  Only LEAF tensors that already own a
+        gradient qualify (parameters after zero_grad): for them `add_grad(g)` is exactly `self.grad += g`
+        (tensor.py:118), which a kernel with an accumulate flag does without materialising g."""
+        if self._requires_grad and self._ctx is None and self._grad is not None and not self._grad_shared:
+            return self._grad
+        return None
+
     def zero_grad(self, traverse_graph: bool = False) -> None:
         if not traverse_graph:
             self._zero_own_grad()

@@ -21,6 +21,7 @@ namespace lg {
 
 struct RedDesc {
     int     nk, nr;                       // kept / reduced dims after collapsing (each >= 1)
+    int     accumulate;                   // final pass only: out += result instead of out = result
     int64_t n_out, rlen;
     int64_t kshape[LG_MAX_DIMS], kstride[LG_MAX_DIMS];
     int64_t rshape[LG_MAX_DIMS], rstride[LG_MAX_DIMS];
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) red_rows_wave(const float* __restrict__ i
         for (int64_t i = lane; i < n; i += 64) acc = Red<OP>::comb(acc, p[i]);
     }
     acc = wave_reduce<OP>(acc);
-    if (lane == 0) out[row] = acc;
+    if (lane == 0) out[row] = d.accumulate ? out[row] + acc : acc;
 }
 
 template <int OP>
@@ -116,7 +117,11 @@ __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ 
     if (lane == 0) wsum[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0)
-        partial[row * splits + split] = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
+    {
+        const float v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
+        float* dst = partial + row * splits + split;
+        *dst = d.accumulate ? *dst + v : v;
+    }
 }
 
 // ---- cols / general: one thread per output element --------------------------------------------
@@ -162,7 +167,9 @@ __global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, fl
             }
         }
     }
-    partial[split * d.n_out + o] = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+    const float v = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+    float* dst = partial + split * d.n_out + o;
+    *dst = d.accumulate ? *dst + v : v;
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -214,8 +221,11 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
         float* partial = nullptr;
         int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
         if (rc != LG_OK) return rc;
-        hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, partial, d, seg);
+        RedDesc d1 = d;
+        d1.accumulate = 0;
+        hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, partial, d1, seg);
         RedDesc d2{};
+        d2.accumulate = d.accumulate;
         d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
         d2.kshape[0] = d.n_out; d2.kstride[0] = splits; d2.rshape[0] = splits; d2.rstride[0] = 1;
         hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, partial, out, d2);
@@ -241,8 +251,11 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
     float* partial = nullptr;
     int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
     if (rc != LG_OK) return rc;
-    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, s, in, partial, d, chunk);
+    RedDesc d1 = d;
+    d1.accumulate = 0;
+    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, s, in, partial, d1, chunk);
     RedDesc d2{};
+    d2.accumulate = d.accumulate;
     d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
     d2.kshape[0] = d.n_out; d2.kstride[0] = 1; d2.rshape[0] = splits; d2.rstride[0] = d.n_out;
     hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, partial, out, d2, splits);
@@ -253,9 +266,18 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
 
 using namespace lg;
 
+extern "C" int lg_reduce_acc(int op, int ndim, const int64_t* shape, const void* in, const int64_t* in_strides,
+                             uint32_t axis_mask, void* out, int accumulate);
+
 extern "C" int lg_reduce(int op, int ndim, const int64_t* shape, const void* in, const int64_t* in_strides,
                          uint32_t axis_mask, void* out) {
+    return lg_reduce_acc(op, ndim, shape, in, in_strides, axis_mask, out, 0);
+}
+
+extern "C" int lg_reduce_acc(int op, int ndim, const int64_t* shape, const void* in, const int64_t* in_strides,
+                             uint32_t axis_mask, void* out, int accumulate) {
     LG_REQUIRE_INIT();
+    LG_ARG(!accumulate || op == LG_RED_SUM, "lg_reduce_acc: accumulate is defined for sums only");
     LG_ARG(ndim >= 0 && ndim <= LG_MAX_DIMS, "lg_reduce: ndim %d out of range [0, %d]", ndim, LG_MAX_DIMS);
     LG_ARG(in != nullptr && out != nullptr, "lg_reduce: NULL pointer");
     LG_ARG(ndim == 0 || (shape != nullptr && in_strides != nullptr), "lg_reduce: NULL shape/strides");
@@ -263,6 +285,7 @@ extern "C" int lg_reduce(int op, int ndim, const int64_t* shape, const void* in,
     LG_ARG((axis_mask >> ndim) == 0, "lg_reduce: axis_mask 0x%x names a dimension >= ndim %d", axis_mask, ndim);
 
     RedDesc d{};
+    d.accumulate = accumulate ? 1 : 0;
     int nk = 0, nr = 0;
     d.n_out = 1;
     d.rlen = 1;
@@ -279,6 +302,7 @@ extern "C" int lg_reduce(int op, int ndim, const int64_t* shape, const void* in,
     if (d.n_out == 0) return LG_OK;
     if (d.rlen == 0) {
         LG_ARG(op == LG_RED_SUM, "lg_reduce: zero-size reduction has no identity for max/min");
+        if (accumulate) return LG_OK;
         uint64_t zero = 0;
         int64_t n = d.n_out, one = 1;
         return lg_fill_strided(4, 1, &n, out, &one, zero);

@@ -252,7 +252,7 @@ def main():
     del p, q, r
 
     # ------------------------------------------------------------------ tiny-BERT forward + backward (BASELINE config #5)
-    bert_ms = None
+    bert_ms = bert_graph_ms = None
     try:
         import importlib.util
         spec = importlib.util.spec_from_file_location("bert_example", os.path.join(ROOT, "examples", "bert.py"))
@@ -276,6 +276,19 @@ def main():
             bert_iter()
         fence()
         bert_ms = 1e3 * wall_max(time.perf_counter() - t0) / 10
+        from lightgrad_amd.autograd.hip import HipGraph as _Graph
+        bgraph = _Graph()
+        with bgraph.capture():
+            bert_iter()
+        for _ in range(3):
+            bgraph.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            bgraph.replay()
+        fence()
+        bert_graph_ms = 1e3 * wall_max(time.perf_counter() - t0) / 20
+        bgraph.destroy()
         del bmodel
     except Exception as e:            # the BERT row is "next" scope: never let it take the headline numbers down
         bert_ms = "failed: %r" % (e,)
@@ -324,7 +337,8 @@ def main():
                           "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
                           "scaling": "replicas", "gemm_kernel_tflops": {k: round(v, 2) for k, v in gemm_tf.items()}},
             "tiny_bert_fwd_bwd": {"ms_per_iter": bert_ms if isinstance(bert_ms, str) else round(bert_ms, 3), "batch": 8, "seq_len": 128,
-                                  "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522", "dispatch": "eager python tape"},
+                                  "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522", "dispatch": "eager python tape",
+                                  "ms_per_iter_hipgraph": round(bert_graph_ms, 3) if bert_graph_ms else None},
             "roofline": roofline,
             "roofline_hbm": hbm,
             "cpu_baseline": cpu_baseline,

@@ -46,12 +46,19 @@ class BertEmbedding(nn.Module):
         self.position_embeddings = Embedding(hidden_size, max_position_embeddings)
         self.token_type_embeddings = Embedding(hidden_size, type_vocab_size)
         self.LayerNorm = nn.LayerNorm(hidden_size)
+        self._const_ids = {}        # (backend class, shape) -> constant id tensors, uploaded once
+
+    def _constant_ids(self, cls, shape):
+        key = (cls, tuple(shape))
+        if key not in self._const_ids:
+            self._const_ids[key] = (cls.from_numpy(np.zeros(shape, dtype=np.int32), requires_grad=False),
+                                    cls.from_numpy(np.arange(shape[-1], dtype=np.int32), requires_grad=False))
+        return self._const_ids[key]
 
     def forward(self, input_ids, token_type_ids=None):
-        cls = input_ids.__class__
+        zeros, position_ids = self._constant_ids(input_ids.__class__, input_ids.shape)
         if token_type_ids is None:
-            token_type_ids = cls.from_numpy(np.zeros(input_ids.shape, dtype=np.int32), requires_grad=False)
-        position_ids = cls.from_numpy(np.arange(input_ids.shape[-1], dtype=np.int32), requires_grad=False)
+            token_type_ids = zeros
         e = self.word_embeddings(input_ids) + self.position_embeddings(position_ids) + self.token_type_embeddings(token_type_ids)
         return self.LayerNorm(e)
 
@@ -146,6 +153,15 @@ class BertForMaskedLM(nn.Module):
         return self.cls.predictions.decoder(h) + self.cls.predictions.bias
 
 
+def forward_backward(model, ids):
+    logits = model(ids)
+    loss = (logits * logits).mean()
+    for p in model.parameters():
+        p.zero_grad()
+    loss.backward()
+    return loss
+
+
 if __name__ == "__main__":
     cpu = "--cpu" in sys.argv
     batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 8
@@ -155,10 +171,17 @@ if __name__ == "__main__":
     ids = to_device(light.from_numpy(np.random.randint(0, TINY["vocab_size"], (batch, 128)).astype(np.int32), requires_grad=False))
     for it in range(3):
         t0 = time.perf_counter()
-        logits = model(ids)
-        loss = (logits * logits).mean()
-        for p in model.parameters():
-            p.zero_grad()
-        loss.backward()
-        value = loss.item()                                   # synchronises
-        print("iter %d: loss %.6f  fwd+bwd %.1f ms" % (it, value, 1e3 * (time.perf_counter() - t0)))
+        value = forward_backward(model, ids).item()            # .item() synchronises
+        print("iter %d: loss %.6f  fwd+bwd %.1f ms (eager tape)" % (it, value, 1e3 * (time.perf_counter() - t0)))
+    if not cpu and "--graph" in sys.argv:
+        # static shapes: record the ~400 launches of one forward+backward once, replay them with one host call
+        from lightgrad_amd.autograd.hip import HipGraph, HipDevice
+        graph = HipGraph()
+        with graph.capture():
+            loss = forward_backward(model, ids)
+        for it in range(3):
+            HipDevice.synchronize()
+            t0 = time.perf_counter()
+            graph.replay()
+            value = loss.item()
+            print("replay %d: loss %.6f  fwd+bwd %.2f ms (hipGraph)" % (it, value, 1e3 * (time.perf_counter() - t0)))

@@ -83,7 +83,7 @@ extern "C" int lg_mse_f32(const float* y, const float* t, float* err, float* los
         hipLaunchKernelGGL(mse_single, dim3(1), dim3(1024), 0, s, y, t, err, loss, n, inv_n,
                            int(aligned16(y) && aligned16(t) && aligned16(err)));
     } else {
-        const unsigned blocks = stream_grid((n + 3) / 4);
+        const unsigned blocks = unsigned(((n + 1023) / 1024) < 4096 ? ((n + 1023) / 1024) : 4096);   // partial sums to combine
         float* partial = nullptr;
         int rc = lg_malloc(reinterpret_cast<void**>(&partial), blocks * sizeof(float));
         if (rc != LG_OK) return rc;

@@ -16,6 +16,7 @@
 // The multi-pass LDS tree of opencl/kernels.py:344-501 is not reproduced.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace lg {
 
@@ -203,7 +204,8 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
             return LG_OK;
         }
         // few long rows: split each row over enough blocks to fill the chip
-        int64_t want_blocks = 2048;
+        static const char* rb_env = getenv("LG_RED_BLOCKS");
+        int64_t want_blocks = rb_env ? atoi(rb_env) : 768;       // measured best for a 512 MiB full sum: 5.77 TB/s (tools/reduce_bench.py)
         int64_t splits = (want_blocks + d.n_out - 1) / d.n_out;
         int64_t min_seg = 4096;                                   // at least 16 KiB per block
         if (splits * min_seg > d.rlen) splits = (d.rlen + min_seg - 1) / min_seg;
@@ -235,8 +237,10 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
     // general / column reduce
     int64_t blocks_x = (d.n_out + 255) / 256;
     int64_t splits = 1;
-    if (blocks_x < 1024 && d.rlen >= 64) {
-        splits = 1024 / blocks_x;
+    static const char* cb_env = getenv("LG_RED_BLOCKS");
+    const int64_t col_blocks = cb_env ? atoi(cb_env) : 1536;     // measured best for sum(axis=0) of 16384 x 8192: 5.81 TB/s
+    if (blocks_x < col_blocks && d.rlen >= 64) {
+        splits = col_blocks / blocks_x;
         if (splits * 16 > d.rlen) splits = d.rlen / 16;           // at least 16 elements per thread
         if (splits < 1) splits = 1;
         if (splits > 65535) splits = 65535;

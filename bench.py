@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--matmul-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="exercise the multi-GPU code path (RCCL communicator, two graphs + eager all-reduce) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
                     help="graph: the step's kernels are captured once in hipGraphs and replayed; eager: python tape every step")
     return ap.parse_args()
@@ -59,7 +61,8 @@ def main():
 
     lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
     info = HipDevice.info()
-    comm = RcclCommunicator(rank, world) if world > 1 else SingleProcess()
+    multi = world > 1 or args.force_comm
+    comm = RcclCommunicator(rank, world) if multi else SingleProcess()
 
     def wall_max(seconds):
         """max over ranks (the slowest rank defines the job's time)"""
@@ -87,6 +90,7 @@ def main():
     model = MLP().map_parameters(lambda p: p.hip())
     use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
     dp = DataParallel(model.parameters(), comm, flatten=use_graph)
+    dp.always_sync = args.force_comm                 # world_size 1: still run the all-reduce
     opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
                                 device_step=use_graph)
     if use_graph:
@@ -116,7 +120,7 @@ def main():
         for _ in range(3):                       # eager: allocates optimizer state, fills the pool, loads kernels
             eager_step()
         n_params = len(opt.parameters)
-        if world == 1:
+        if not multi:
             g_all = HipGraph()
             with g_all.capture():
                 graph_loss = eager_step()
@@ -318,7 +322,7 @@ def main():
                                   "matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s" % (n_cpu, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
                         "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3), "numpy": np.__version__}
 
-    if world > 1:
+    if multi:
         comm.close()
     if rank == 0:
         out = {

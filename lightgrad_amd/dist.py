@@ -240,7 +240,7 @@ class DataParallel(object):
 
     def sync_gradients(self):
         """sum the gradient bucket over all ranks, in place, asynchronously"""
-        if self.comm.world_size > 1:
+        if self.comm.world_size > 1 or getattr(self, "always_sync", False):
             self.comm.allreduce_sum_(self.bucket)
 
     def parameter_digest(self) -> float:

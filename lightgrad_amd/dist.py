@@ -109,6 +109,24 @@ def _exchange_unique_id(rank, make_id, path, timeout=300.0):
     raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout))
 
 
+class _c_stdout_to_stderr(object):
+    """redirect file descriptor 1 to file descriptor 2 for the duration of a `with` block (C libraries included)"""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class RcclCommunicator(Communicator):
     """GPU ranks over RCCL/xGMI; collectives run on liblghip's compute stream"""
 
@@ -129,9 +147,12 @@ class RcclCommunicator(Communicator):
             buf = ctypes.create_string_buffer(128)
             L.comm_check(self._lib.lg_comm_get_unique_id(buf))
             return buf.raw
-        blob = _exchange_unique_id(self.rank, make_id, id_path)
-        L.comm_check(self._lib.lg_comm_init(self.rank, self.world_size, ctypes.create_string_buffer(blob, 128)))
-        self.barrier()
+        # RCCL prints a version banner on the C-level stdout when a communicator is created; programs that
+        # print machine-readable results on stdout (bench.py) must not get it mixed in: send it to stderr
+        with _c_stdout_to_stderr():
+            blob = _exchange_unique_id(self.rank, make_id, id_path)
+            L.comm_check(self._lib.lg_comm_init(self.rank, self.world_size, ctypes.create_string_buffer(blob, 128)))
+            self.barrier()          # first collective: whatever RCCL prints lazily also lands on stderr
         if self.rank == 0:
             try:
                 os.remove(id_path)

@@ -147,6 +147,14 @@ class HipTensor(AbstractTensor):
         a = np.random.uniform(low, high, size=shape).astype(dtype)
         return HipTensor.from_numpy(a, requires_grad=requires_grad)
 
+    @classmethod
+    def xavier(cls, shape, requires_grad: bool = True) -> "HipTensor":
+        # U(-1,1)/sqrt(numel) (tensor.py:85-89) formed on the host exactly as the CPU backend does - numpy divides the
+        # fp32 draw by the float64 sqrt in double and rounds once - so both backends start from identical bits
+        a = np.random.uniform(-1, 1, size=shape).astype(np.float32)
+        a /= np.sqrt(a.size)
+        return HipTensor.from_numpy(a, requires_grad=requires_grad)
+
     @staticmethod
     def from_numpy(a: np.ndarray, requires_grad: bool = True) -> "HipTensor":
         a = np.asarray(a)

@@ -397,33 +397,35 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     // tile choice: largest tile that still yields enough workgroups for 256 CUs
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     LG_ARG(nblocks(32, 32) < (int64_t(1) << 30), "lg_gemm_f32: problem too large for one launch");
+    // Tile choice.  Skinny outputs take the 64x32 / 32x64 tiles.  Otherwise three tiles compete:
+    //   256x256 (16 waves, 1 WG/CU)  132-141 TFLOP/s at 4096^3   128x128 (4 waves)  ~124   64x64 (4 waves, + split-K)  ~107 at 3072^3
+    // and the one with the smallest modelled time wins: (workgroups per CU, rounded up) x tile area / efficiency.  The
+    // model reproduces the measured ranking from 512^3 to 8192^3 (tools/gemm_bench.py; profiles/README.md): small and
+    // awkward sizes prefer many small tiles (3072^3: 64x64 = 107 vs 88-92 TFLOP/s), 4096^3 and up the 256x256 tile.
+    // LG_GEMM_TILE = 0 / 2 / 9 forces 128 / 256 / 64 for experiments.
     int rc;
+    static const char* tile_env = getenv("LG_GEMM_TILE");
+    int tile = tile_env ? atoi(tile_env) : -1;
     if (N <= 32) {
         rc = launch_config<64, 32, 32, 2, 1>(g, akc, bkc, va, vb, batch);
     } else if (M <= 32) {
         rc = launch_config<32, 64, 32, 1, 2>(g, akc, bkc, va, vb, batch);
-    } else if (nblocks(128, 128) >= 384 || (M >= 2048 && N >= 2048)) {
-        // Large problems: 256x256 tiles (16 waves, one workgroup per CU, measured 132-141 TFLOP/s at 4096^3) or
-        // 128x128 tiles (4 waves, two workgroups per CU, 108-124 TFLOP/s).  Pick by modelled time =
-        // rounds over the chip x tile area x workgroups per CU / efficiency, which accounts for edge padding and
-        // for the last, partly filled round.  LG_GEMM_TILE forces a variant (tools/gemm_bench.py).
-        static const char* tile_env = getenv("LG_GEMM_TILE");
-        int tile = tile_env ? atoi(tile_env) : -1;
+    } else {
         if (tile < 0) {
             const int64_t cus = rt().compute_units > 0 ? rt().compute_units : 256;
-            auto cost = [&](int64_t bm, int64_t bn, int64_t per_cu, double eff) {
-                const int64_t rounds = (nblocks(bm, bn) + cus * per_cu - 1) / (cus * per_cu);
-                return double(rounds) * double(bm * bn * per_cu) / eff;
+            auto cost = [&](int64_t bm, int64_t bn, double eff) {
+                const int64_t per_cu = (nblocks(bm, bn) + cus - 1) / cus;
+                return double(per_cu) * double(bm * bn) / eff;
             };
-            tile = cost(256, 256, 1, 0.87) <= cost(128, 128, 2, 0.78) ? 2 : 0;
+            const double c256 = cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
+            tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
         }
         switch (tile) {
-            case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves, 64x64 per wave
-            case 2:  rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break;   // 16 waves, 64x64 per wave
+            case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
+            case 2:  rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break;
+            case 9:  rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
             default: rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
         }
-    } else {
-        rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
     }
     if (rc != LG_OK) return rc;
     LG_CHECK_LAUNCH();

@@ -418,9 +418,21 @@ class dot(Function):
             ga = _gemm(g_flat, _swap_last(b), out_colmajor=False).reshape(*a._shape)
             gb = _gemm(_swap_last(a_flat), g_flat, out_colmajor=_is_colmajor(b))
             return ga, gb
-        ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
-        gb = _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
-        return ga, gb
+        ga = gb = None
+        if len(a._shape) == 2 and len(b._shape) == 2:
+            # dense 2-D leaves that already own a gradient buffer: accumulate in the GEMM epilogue (see linear.backward)
+            acc_a, acc_b = a._grad_accumulator(), b._grad_accumulator()
+            if a.requires_grad and acc_a is not None and acc_a.is_contiguous() and a is not b:
+                _gemm(out_grad, _swap_last(b), accumulate_into=acc_a)
+                ga = False
+            if b.requires_grad and acc_b is not None and acc_b.is_contiguous() and a is not b:
+                _gemm(_swap_last(a), out_grad, accumulate_into=acc_b)
+                gb = False
+        if ga is None:
+            ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
+        if gb is None:
+            gb = _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
+        return (None if ga is False else ga), (None if gb is False else gb)
 
 
 """ In-place operators: no backward; the result aliases the input storage (cpu/ops.py:120-153) """

@@ -271,13 +271,20 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             const int64_t row0 = m0 + (wm * TM + i) * 32 + 4 * h;
             if (col < g.N) {
                 const float bv = bias ? bias[col] : 0.f;
+                float old[16];
+                if (accumulate) {      // C += ...: fetch the 16 old values first so the loads overlap, then add and store
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
+                        old[e] = row < g.M ? C[row * ldc + col] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
                     if (row < g.M) {
-                        float* p = C + row * ldc + col;
                         const float val = bias ? acc[i][j][e] + bv : acc[i][j][e];
-                        *p = accumulate ? *p + val : val;
+                        C[row * ldc + col] = accumulate ? old[e] + val : val;
                     }
                 }
             }

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--matmul-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bert", action="store_true", help="skip the tiny-BERT forward+backward timing")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
     ap.add_argument("--force-comm", action="store_true",
                     help="exercise the multi-GPU code path (RCCL communicator, two graphs + eager all-reduce) with world_size 1")
@@ -258,6 +259,8 @@ def main():
     # ------------------------------------------------------------------ tiny-BERT forward + backward (BASELINE config #5)
     bert_ms = bert_graph_ms = None
     try:
+        if args.no_bert:
+            raise RuntimeError("skipped (--no-bert)")
         import importlib.util
         spec = importlib.util.spec_from_file_location("bert_example", os.path.join(ROOT, "examples", "bert.py"))
         bert = importlib.util.module_from_spec(spec)
@@ -284,14 +287,16 @@ def main():
         bgraph = _Graph()
         with bgraph.capture():
             bert_iter()
-        for _ in range(3):
+        # few replays on purpose: rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch once ~16 000 graph kernel
+        # nodes have been replayed in one process (40 x this ~400-node graph; 3 replays are fine) - keep bench.py profilable
+        for _ in range(2):
             bgraph.replay()
         fence()
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(6):
             bgraph.replay()
         fence()
-        bert_graph_ms = 1e3 * wall_max(time.perf_counter() - t0) / 20
+        bert_graph_ms = 1e3 * wall_max(time.perf_counter() - t0) / 6
         bgraph.destroy()
         del bmodel
     except Exception as e:            # the BERT row is "next" scope: never let it take the headline numbers down

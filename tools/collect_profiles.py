@@ -1,0 +1,32 @@
+"""Run HERE after tools/refresh_profiles.sh ran on the GPU box: copies the judged artefacts from gpurun_out/final into
+profiles/<round>/ and rewrites pmc_traffic.json.   python tools/collect_profiles.py r1 v3"""
+import collections, csv, glob, json, os, shutil, sys
+rnd, tag = sys.argv[1], sys.argv[2]
+src, dst = "gpurun_out/final", os.path.join("profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_%s.json" % tag))
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "bench_under_rocprof_%s.json" % tag))
+shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], os.path.join(dst, "bench_kernel_stats_%s.csv" % tag))
+shutil.copy(os.path.join(src, "mlp_step_trace.txt"), os.path.join(dst, "mlp_step_trace_%s.txt" % tag))
+shutil.copy(os.path.join(src, "gemm_sweep.txt"), os.path.join(dst, "gemm_sweep_%s.txt" % tag))
+pmc = {}
+for kind in ("fetch", "write"):
+    f = glob.glob("%s/%s/*/*_counter_collection.csv" % (src, kind))[0]
+    shutil.copy(f, os.path.join(dst, "pmc_%s_size_%s.csv" % (kind, tag)))
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc.setdefault(k, {})[kind] = sum(v) / len(v)
+for k, v in sorted(pmc.items()):
+    print("%-110s FETCH %10.1f KB  WRITE %10.1f KB" % (k[:110], v.get("fetch", 0), v.get("write", 0)))
+nn = [v for k, v in pmc.items() if "sgemm_mfma<256, 256, 32, 4, 4, true, false" in k][0]
+json.dump({"sgemm_mfma_256x256_NN_4096": {
+    "fetch_size_kb_raw": nn["fetch"], "write_size_kb": nn["write"],
+    "hbm_bytes_per_launch": int((2 * nn["fetch"] + nn["write"]) * 1024), "algorithmic_bytes_per_launch": 3 * 4096 * 4096 * 4,
+    "correction": "FETCH_SIZE doubled (gfx950 reports half of a 16 B/lane read: MI355X_MICROARCH.md HBM section), WRITE_SIZE exact; KB -> bytes x1024",
+    "source": "profiles/%s/pmc_fetch_size_%s.csv, pmc_write_size_%s.csv (rocprofv3 --pmc, one counter per pass, tools/profile_kernels.py)" % (rnd, tag, tag)}},
+    open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+d = json.load(open(os.path.join(src, "bench.json")))
+print(json.dumps({k: d[k] for k in ("value", "ms_per_step", "secondary", "roofline", "tiny_bert_fwd_bwd", "cpu_baseline")}, indent=0)[:2500])
+print({k: v["GB/s"] for k, v in d["roofline_hbm"].items()})

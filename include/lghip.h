@@ -76,6 +76,9 @@ int lg_pool_stats(uint64_t* reserved_bytes, uint64_t* in_use_bytes, uint64_t* hi
 int lg_memcpy_h2d(void* dst, const void* src, size_t bytes);   /* returns after src may be reused */
 int lg_memcpy_d2h(void* dst, const void* src, size_t bytes);   /* synchronises the stream */
 int lg_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* stream-ordered */
+/* upload without waiting: src is staged into pinned memory (reusable on return), the DMA is stream-ordered.
+ * Feeds a new batch into the static input tensor of a captured graph between two lg_graph_launch calls. */
+int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes);
 
 /* HIP events on the library's stream (timing in bench.py) */
 int lg_event_create(void** ev);

@@ -167,6 +167,19 @@ class HipTensor(AbstractTensor):
 
     """ Data movement """
 
+    def upload_(self, a: np.ndarray) -> "HipTensor":
+        """overwrite this (dense) tensor with a host array of the same shape and dtype WITHOUT waiting: the data is
+        staged in pinned memory and copied by a stream-ordered DMA.  This is how a training loop refreshes the static
+        input tensors of a captured graph (autograd/hip/graph.py) between two replays."""
+        a = np.asarray(a)
+        assert self.is_contiguous() and a.shape == self._shape and a.dtype == self._dtype, \
+            "upload_: need a dense tensor and an array of shape %s / dtype %s" % (self._shape, self._dtype)
+        if not a.flags["C_CONTIGUOUS"]:
+            a = a.copy(order="C")
+        if a.nbytes > 0:
+            _l.check(_l.lib().lg_memcpy_h2d_async(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
     def is_contiguous(self) -> bool:
         expect = 1
         for s, st in zip(reversed(self._shape), reversed(self._strides)):

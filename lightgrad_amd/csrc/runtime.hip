@@ -259,6 +259,48 @@ int lg_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     return LG_OK;
 }
 
+// Asynchronous upload through a ring of pinned staging buffers: the host data is copied into pinned memory
+// (so `src` is reusable on return), the DMA to the device is stream-ordered and nobody waits for it.  This is how a
+// training loop feeds a new batch into the static input tensor of a captured graph without stalling the stream.
+namespace {
+struct Staging {
+    void*      host = nullptr;
+    size_t     bytes = 0;
+    hipEvent_t done = nullptr;
+    bool       busy = false;
+};
+constexpr int kStagingSlots = 4;
+Staging g_staging[kStagingSlots];
+int g_staging_next = 0;
+}  // namespace
+
+int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes) {
+    LG_REQUIRE_INIT();
+    if (bytes == 0) return LG_OK;
+    LG_ARG(dst && src, "lg_memcpy_h2d_async: NULL pointer");
+    LG_ARG(!capturing(), "lg_memcpy_h2d_async: host transfers cannot be captured; upload between graph launches");
+    Staging& st = g_staging[g_staging_next];
+    g_staging_next = (g_staging_next + 1) % kStagingSlots;
+    if (st.busy) {                       // the DMA that last used this slot must have finished
+        LG_HIP(hipEventSynchronize(st.done));
+        st.busy = false;
+    }
+    if (st.bytes < bytes) {
+        if (st.host) LG_HIP(hipHostFree(st.host));
+        st.host = nullptr;
+        st.bytes = 0;
+        size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+        LG_HIP(hipHostMalloc(&st.host, want, hipHostMallocDefault));
+        st.bytes = want;
+    }
+    if (!st.done) LG_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    memcpy(st.host, src, bytes);
+    LG_HIP(hipMemcpyAsync(dst, st.host, bytes, hipMemcpyHostToDevice, rt().stream));
+    LG_HIP(hipEventRecord(st.done, rt().stream));
+    st.busy = true;
+    return LG_OK;
+}
+
 int lg_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     LG_REQUIRE_INIT();
     if (bytes == 0) return LG_OK;

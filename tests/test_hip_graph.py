@@ -78,3 +78,52 @@ def test_capture_rejects_host_transfers(hip):
         b = a * 3.0
     g2.replay()
     np.testing.assert_array_equal(b.numpy(), np.full((4, 4), 3, np.float32))
+
+
+def test_graph_with_new_batches_through_async_upload(hip):
+    """a captured step fed with a different batch per replay (upload_ into the static inputs) == the eager loop"""
+    from lightgrad_amd.autograd.hip import HipGraph
+    rng = np.random.RandomState(0)
+    batches = [(rng.uniform(0, 1, (16, 20)).astype(np.float32), np.eye(10, dtype=np.float32)[rng.randint(0, 10, 16)]) for _ in range(6)]
+
+    def make():
+        np.random.seed(5)
+        model = MLP(20, 16, 10).map_parameters(lambda p: p.hip())
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=True, device_step=True)
+        return model, opt
+    # eager reference
+    model_e, opt_e = make()
+    eager = []
+    for x, t in batches:
+        l = light.loss.mse(model_e(hip.from_numpy(x)), hip.from_numpy(t))
+        opt_e.zero_grad()
+        l.backward()
+        opt_e.step()
+        eager.append(l.item())
+    # graph: first two batches eagerly (warm-up), the rest by replay with uploads
+    model_g, opt_g = make()
+    xs, ts = hip.from_numpy(batches[0][0]), hip.from_numpy(batches[0][1])
+
+    def step():
+        l = light.loss.mse(model_g(xs), ts)
+        opt_g.zero_grad()
+        l.backward()
+        opt_g.step()
+        return l
+    got = [step().item()]
+    xs.upload_(batches[1][0])
+    ts.upload_(batches[1][1])
+    got.append(step().item())
+    graph = HipGraph()
+    with graph.capture():
+        loss = step()
+    opt_g.t -= 4
+    for x, t in batches[2:]:
+        xs.upload_(x)
+        ts.upload_(t)
+        graph.replay()
+        opt_g.on_graph_replay()
+        got.append(loss.item())
+    np.testing.assert_allclose(got, eager, rtol=1e-6)
+    for p, q in zip(model_e.parameters(), model_g.parameters()):
+        np.testing.assert_allclose(q.numpy(), p.numpy(), rtol=1e-6, atol=1e-7)

@@ -2,7 +2,7 @@
 the BASELINE shapes 784 -> 512 -> 10, batch 1024; the real dataset needs network access).  A NEW batch is
 generated on the host and uploaded EVERY step, so the printed rate is the PCIe-inclusive one.
 
-    python examples/mnist.py [--cpu] [--steps 200] [--graph]
+    python examples/mnist.py [--cpu] [--steps 200] [--graph] [--cnn]
 
 --graph: the step is captured once into a hipGraph; every iteration uploads the batch into the graph's static
 input tensors (pinned staging, asynchronous) and replays the graph.
@@ -29,6 +29,20 @@ class NN(nn.Module):
         return self.l2(self.l1(x.reshape(-1, 28 * 28)).relu())
 
 
+class CNN(nn.Module):
+    """ the reference's examples/mnist.py:14-22 """
+    def __init__(self):
+        nn.Module.__init__(self)
+        self.c1 = nn.Conv2d(1, 8, kernelsize=3, bias=False, pad=0)
+        self.c2 = nn.Conv2d(8, 16, kernelsize=3, bias=False, pad=0)
+        self.l1 = nn.Linear(5 * 5 * 16, 10)
+
+    def forward(self, x):
+        y = self.c1(x).max_pool().relu()
+        y = self.c2(y).max_pool().relu()
+        return self.l1(y.reshape(-1, 5 * 5 * 16))
+
+
 def synthetic_batch(rng, batch):
     x = rng.uniform(0, 1, (batch, 1, 28, 28)).astype(np.float32)
     labels = rng.randint(0, 10, batch)
@@ -41,12 +55,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--cnn", action="store_true", help="the convolutional model instead of the MLP")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=1024)
     args = ap.parse_args()
     to_device = (lambda t: t) if args.cpu else (lambda t: t.hip())
     np.random.seed(0)
-    model = NN().map_parameters(to_device)
+    model = (CNN() if args.cnn else NN()).map_parameters(to_device)
     rng = np.random.RandomState(1)
     batches = [synthetic_batch(rng, args.batch) for _ in range(8)]       # host-side data, re-uploaded every step
     losses = []

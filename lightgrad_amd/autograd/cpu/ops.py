@@ -386,3 +386,54 @@ class sum(Function):
             axes = tuple(sorted(a % len(shape) for a in axes))
             out_grad = np.expand_dims(out_grad, axis=axes) if len(shape) > 0 else out_grad
         return np.broadcast_to(out_grad, shape)
+
+
+""" Convolution (CNN example; reference cpu/ops.py:298-356) """
+
+
+def _conv_strides(strides, n):
+    """per-window-axis strides; the first window axis is the channel axis and always moves by 1"""
+    if isinstance(strides, int):
+        return (1,) + (strides,) * (n - 1) if n > 1 else (strides,)
+    strides = tuple(strides)
+    return (1,) + strides if len(strides) == n - 1 else strides
+
+
+def _windows(x, kshape, strides):
+    """read-only view of all `kshape` windows over the trailing len(kshape) axes: (..., out positions..., window...)"""
+    n = len(kshape)
+    out = tuple((d - k) // s + 1 for d, k, s in zip(x.shape[-n:], kshape, strides))
+    st = x.strides[:-n] + tuple(a * s for a, s in zip(x.strides[-n:], strides)) + x.strides[-n:]
+    return np.lib.stride_tricks.as_strided(x, shape=x.shape[:-n] + out + tuple(kshape), strides=st, writeable=False)
+
+
+@_op()
+class conv(Function):
+    """ valid N-d cross-correlation: t (..., C, d1..dm), kernel (out_c, C, k1..km) -> (..., out_c, o1..om), computed as
+    one matrix product of the window matrix with the flattened kernel; strides apply to the spatial axes """
+    def forward(ctx, t, kernel, strides=1):
+        n = kernel.ndim - 1
+        st = _conv_strides(strides, n)
+        assert t.ndim >= n and len(st) == n
+        win = _windows(t, kernel.shape[1:], st)
+        cols = win.reshape(-1, int(np.prod(kernel.shape[1:])))
+        w2 = kernel.reshape(kernel.shape[0], -1)
+        y = cols @ w2.T
+        ctx.save_for_backward(cols, w2, t.shape, kernel.shape, st, win.shape)
+        y = y.reshape(*win.shape[:-n], -1)                     # (..., o0, o1..om, out_c) with o0 the channel position (1)
+        return np.ascontiguousarray(np.squeeze(np.swapaxes(y, -n - 1, -1), -1))
+
+    def backward(ctx, out_grad):
+        cols, w2, in_shape, k_shape, st, win_shape = ctx.get_saved_tensors()
+        n = len(k_shape) - 1
+        g2 = np.moveaxis(out_grad, -n, -1).reshape(-1, k_shape[0])
+        dw = (g2.T @ cols).reshape(k_shape)
+        dwin = (g2 @ w2).reshape(win_shape)
+        dx = np.zeros(in_shape, dtype=np.float32)
+        lead = len(in_shape) - n
+        out_pos = win_shape[lead:lead + n]
+        # every window offset contributes one strided slab of the input gradient (slabs of one offset never overlap)
+        for off in np.ndindex(*k_shape[1:]):
+            dst = (Ellipsis,) + tuple(slice(o, o + s * p, s) for o, s, p in zip(off, st, out_pos))
+            dx[dst] += dwin[(Ellipsis,) + off]
+        return dx, dw

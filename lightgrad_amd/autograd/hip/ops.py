@@ -674,6 +674,69 @@ max = HipTensor.register_op("max", _extremum("max", _l.RED_MAX, "every tied maxi
 min = HipTensor.register_op("min", _extremum("min", _l.RED_MIN, "cpu/ops.py:274-286"))
 
 
+""" Convolution (CNN example, SURVEY.md §8f row 4 tail): window VIEW -> one gather copy -> MFMA GEMM """
+
+
+def _conv_strides(strides, n):
+    if isinstance(strides, int):
+        return (1,) + (strides,) * (n - 1) if n > 1 else (strides,)
+    strides = tuple(strides)
+    return (1,) + strides if len(strides) == n - 1 else strides
+
+
+@HipTensor.register_op()
+class conv(Function):
+    """ valid N-d cross-correlation t (..., C, d1..dm) * kernel (out_c, C, k1..km) -> (..., out_c, o1..om) with the
+    semantics of cpu/ops.py:298-356.  All windows are ONE strided (overlapping) view of the input - no im2col loop -
+    gathered once into the window matrix, which the SGEMM kernel multiplies with the flattened kernel.  backward:
+    two GEMMs, then one strided in-place add per spatial kernel offset (slabs of one offset never overlap).  The
+    reference's OpenCL backend has a direct kernel and no backward (opencl/ops.py:403-408). """
+    def forward(ctx, t, kernel, strides=1):
+        _require_f32(t, kernel)
+        n = len(kernel._shape) - 1
+        st = _conv_strides(strides, n)
+        kshape = kernel._shape[1:]
+        assert len(t._shape) >= n and len(st) == n and t._shape[-n] == kshape[0], \
+            "conv: input %s does not match kernel %s" % (t._shape, kernel._shape)
+        out_pos = tuple((d - k) // s + 1 for d, k, s in zip(t._shape[-n:], kshape, st))
+        # window view without the channel-position axis (its extent is 1): (..., o1..om, C, k1..km)
+        wshape = t._shape[:-n] + out_pos[1:] + kshape
+        wstrides = t._strides[:-n] + tuple(a * s for a, s in zip(t._strides[-n + 1:], st[1:])) + t._strides[-n:]
+        assert len(wshape) <= 8, "conv: window view needs %d dims (max 8)" % len(wshape)
+        win = HipTensor(t.data, wshape, wstrides, t._offset, t._dtype)
+        ncol = 1
+        for k in kshape:
+            ncol *= k
+        cols = win.contiguous().reshape(-1, ncol)
+        w2 = kernel.reshape(kernel._shape[0], ncol)
+        y = _gemm(cols, _swap_last(w2))                                           # (P, out_c)
+        ctx.save_for_backward(cols, w2, t._shape, kernel._shape, st, out_pos)
+        lead = len(t._shape) - n
+        y = y.reshape(*t._shape[:lead], *out_pos[1:], kernel._shape[0])
+        perm = tuple(range(lead)) + (len(y._shape) - 1,) + tuple(range(lead, len(y._shape) - 1))
+        return y.transpose(*perm).contiguous()
+
+    def backward(ctx, out_grad):
+        cols, w2, in_shape, k_shape, st, out_pos = ctx.get_saved_tensors()
+        n = len(k_shape) - 1
+        lead = len(in_shape) - n
+        m = len(out_grad._shape)
+        perm = tuple(range(lead)) + tuple(range(lead + 1, m)) + (lead,)                # out_c last
+        g2 = out_grad.transpose(*perm).reshape(-1, k_shape[0])
+        dw = _gemm(_swap_last(g2), cols).reshape(*k_shape)
+        dwin = _gemm(g2, w2).reshape(*in_shape[:lead], *out_pos[1:], *k_shape[1:])   # (..., o1..om, C, k1..km)
+        dx = HipTensor.zeros(in_shape, requires_grad=False)
+        nsp = n - 1                                                                     # spatial axes
+        for off in np.ndindex(*k_shape[2:]):
+            src = _idx_view(dwin, (Ellipsis,) + off)                                   # (..., o1..om, C)
+            ms = len(src._shape)
+            src = src.transpose(*(tuple(range(lead)) + (ms - 1,) + tuple(range(lead, ms - 1))))   # (..., C, o1..om)
+            dst = _idx_view(dx, (Ellipsis,) + tuple(slice(o, o + s * p, s) for o, s, p in zip(off, st[1:], out_pos[1:])))
+            _binary(_l.EW_ADD, dst, src, out=dst)
+        assert nsp == len(k_shape) - 2
+        return dx, dw
+
+
 """ Fused forms used by nn / optim / loss (SURVEY.md §8f row 1) """
 
 

@@ -109,6 +109,20 @@ class Linear(Module):
         return (y + self.bias) if self.bias is not None else y
 
 
+class Conv2d(Module):
+    """ valid 2-d convolution with optional zero padding: `x.pad(p).conv(w, strides=s) + b` (reference nn.py:98-107) """
+
+    def __init__(self, in_channels: int, out_channels: int, kernelsize: int = 3, stride: int = 1, pad: int = None, bias: bool = True):
+        Module.__init__(self)
+        self.w = Tensor.xavier((out_channels, in_channels, kernelsize, kernelsize))
+        self.b = Tensor.xavier((1, out_channels, 1, 1)) if bias else None
+        self.s, self.p = stride, (kernelsize // 2) if pad is None else pad
+
+    def forward(self, x):
+        y = (x.pad(self.p) if self.p > 0 else x).conv(self.w, strides=self.s)
+        return (y + self.b) if self.b is not None else y
+
+
 class LayerNorm(Module):
 
     def __init__(self, shape: tuple, eps: float = 1e-5):

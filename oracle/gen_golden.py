@@ -149,6 +149,36 @@ def main():
     np.savez_compressed(os.path.join(OUT, "mlp_small_adam.npz"), **mlp_traj(20, 16, 10, 8, 12, "adam", 8, True))
     np.savez_compressed(os.path.join(OUT, "mlp_small_sgd.npz"), **mlp_traj(20, 16, 10, 8, 12, "sgd", 9, True))
     np.savez_compressed(os.path.join(OUT, "mlp_full_adabelief.npz"), **mlp_traj(784, 512, 10, 1024, 5, "adabelief", 0, False))
+    # ---------------------------------------------------------------- CNN ops: conv (all dims / strides), pad, pooling
+    cnn = {}
+    rng2 = np.random.RandomState(77)
+
+    def run_cnn(name, fn, inputs):
+        ts = [T.from_numpy(a.copy()) for a in inputs]
+        y = fn(*ts)
+        w = f32(rng2, -1, 1, y.shape)
+        (y * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        cnn[name + "/out"], cnn[name + "/w"] = np.array(y.numpy()), w
+        for i, (a, t) in enumerate(zip(inputs, ts)):
+            cnn["%s/in%d" % (name, i)] = a
+            cnn["%s/grad%d" % (name, i)] = np.array(t.grad.numpy())
+    for dim in (1, 2, 3):
+        for size, k, stride, cin, cout in [(6, 3, 1, 2, 3), (9, 3, 2, 1, 2), (9, 5, 3, 3, 1), (7, 7, 1, 2, 2)]:
+            if dim == 3 and size == 9:
+                size = 7 if k <= 3 else 9
+            if k > size:
+                continue
+            xin = f32(rng2, -1, 1, (2, cin) + (size,) * dim)
+            kin = f32(rng2, -1, 1, (cout, cin) + (k,) * dim)
+            run_cnn("conv%dd_s%d_k%d_st%d_c%d_%d" % (dim, size, k, stride, cin, cout), lambda a, b, st=stride: a.conv(b, strides=st), [xin, kin])
+    img = f32(rng2, -1, 1, (2, 3, 7, 6))
+    run_cnn("pad2", lambda a: a.pad(2), [img])
+    run_cnn("pad_1_3", lambda a: a.pad((1, 3), value=0.5), [img])
+    run_cnn("max_pool", lambda a: a.max_pool(), [img])
+    run_cnn("min_pool_3x2", lambda a: a.min_pool(kernel=(3, 2)), [img])
+    run_cnn("max_pool_2x3", lambda a: a.max_pool(kernel=(2, 3)), [img])
+    np.savez_compressed(os.path.join(OUT, "cnn_ops.npz"), **cnn)
+
     # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
     # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
     # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.

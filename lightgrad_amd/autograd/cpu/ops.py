@@ -11,7 +11,7 @@ backend as SURVEY.md §8c prescribes:
     gradient to the input shape                       (opencl/ops.py:353-368)
   * `dot.backward` for batched operands swaps the last two axes instead of
     reversing all axes                                (opencl/ops.py:127-132)
-`conv` (cpu/ops.py:298-356) is CNN-only and out of scope.
+`conv` (cpu/ops.py:298-356) is restated at the end of this file for the CNN example (SURVEY.md §8f row 4 tail).
 """
 import numpy as np
 from ..func import Function

@@ -54,6 +54,9 @@ def main():
     else:
         world, rank = 1, 0
 
+    if not os.path.exists(os.path.join(ROOT, "lightgrad_amd", "liblghip.so")) and rank == 0:
+        import subprocess            # the built library normally travels with the tree; compile it if it did not
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lightgrad_amd", "csrc"), "-j", "8"], check=True, stdout=sys.stderr)
     import numpy as np
     import lightgrad_amd as light
     from lightgrad_amd import HipTensor

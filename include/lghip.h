@@ -222,10 +222,12 @@ int lg_counter_add_i64(int64_t* counter, int64_t delta);
 
 /* All parameters of a model in one launch: p, g, m, v are flat buckets holding `nseg` (<= 64) parameters
  * back to back, parameter j occupying [offsets[j], offsets[j+1]); its step number is
- * t = *step * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32. */
+ * t = step[0] * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32.  `step` points at TWO int64:
+ * step[0] the optimizer step, step[1] an arrival ticket that must be 0 between launches; with advance != 0
+ * the last workgroup to finish increments step[0] (no separate counter launch). */
 int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
                           double lr, double b1, double b2, double eps,
-                          const int64_t* step, double gscale, int belief);
+                          int64_t* step, double gscale, int belief, int advance);
 
 /* ---- fused loss ----------------------------------------
  * loss.mse forward (loss.py:4-10) for dense fp32 tensors of n elements:

@@ -22,6 +22,8 @@ from . import lib as _l
 
 class HipGraph(object):
 
+    capturing = False         # True inside a `capture()` block (kernels are being recorded, not executed)
+
     def __init__(self):
         self._exec = None
 
@@ -30,14 +32,17 @@ class HipGraph(object):
         assert self._exec is None, "HipGraph already holds a captured graph"
         L = _l.lib()
         _l.check(L.lg_graph_begin())
+        HipGraph.capturing = True
         handle = ctypes.c_void_p()
         try:
             yield self
         except BaseException:
+            HipGraph.capturing = False
             L.lg_graph_end(ctypes.byref(handle))     # leave capture mode, drop whatever was recorded
             if handle.value:
                 L.lg_graph_destroy(handle)
             raise
+        HipGraph.capturing = False
         _l.check(L.lg_graph_end(ctypes.byref(handle)))
         self._exec = handle
 

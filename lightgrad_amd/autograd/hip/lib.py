@@ -71,7 +71,7 @@ PROTOTYPES = {
                                      c_double, c_void_p, c_int64, c_int64, c_double, c_int]),
     "lg_counter_add_i64": (c_int, [c_void_p, c_int64]),
     "lg_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
-                                      c_double, c_void_p, c_double, c_int]),
+                                      c_double, c_void_p, c_double, c_int, c_int]),
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_mse_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),

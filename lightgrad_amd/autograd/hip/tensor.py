@@ -165,6 +165,21 @@ class HipTensor(AbstractTensor):
             _l.check(_l.lib().lg_memcpy_h2d(t.ptr, a.ctypes.data, a.nbytes))
         return t
 
+    _unit_seeds = {}          # shape -> constant tensor of ones used as the backward seed of item tensors
+
+    def _seed_gradient(self):
+        # the seed of a loss is always the same one-element tensor: keep ONE read-only constant per shape instead of
+        # an allocation + fill kernel per backward pass (shared=True: the tape never writes into it)
+        if self._shape in ((), (1,)) and self._dtype == np.float32:
+            seed = HipTensor._unit_seeds.get(self._shape)
+            if seed is None:
+                from .graph import HipGraph
+                if not HipGraph.capturing:      # while capturing, a fill would only be recorded, not executed
+                    seed = HipTensor._unit_seeds[self._shape] = HipTensor.ones(self._shape, requires_grad=False)
+            if seed is not None:
+                return seed, True
+        return HipTensor.ones(self._shape, dtype=self._dtype, requires_grad=False), False
+
     """ Data movement """
 
     def upload_(self, a: np.ndarray) -> "HipTensor":
@@ -247,12 +262,13 @@ class HipTensor(AbstractTensor):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         assert offsets[-1] == self.numel()
         _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
-                                                lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0))
+                                                lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 1))
+        # (advance = 1: the kernel's last workgroup increments the step counter itself)
 
     @staticmethod
     def _new_step_counter(step: int) -> "HipTensor":
-        """device-resident optimizer step number (int64) for graph-captured training steps"""
-        return HipTensor.from_numpy(np.asarray([step], dtype=np.int64), requires_grad=False)
+        """device-resident optimizer step number for graph-captured training steps: int64[2] = (step, arrival ticket)"""
+        return HipTensor.from_numpy(np.asarray([step, 0], dtype=np.int64), requires_grad=False)
 
     def _fused_adam_step_dev(self, grad, m, v, lr, b1, b2, eps, step_counter, t_mul, t_add, grad_scale, belief):
         """like `_fused_adam_step`, but t = step_counter * t_mul + t_add is evaluated on the device"""

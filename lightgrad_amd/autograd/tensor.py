@@ -133,11 +133,15 @@ class AbstractTensor(metaclass=_TensorType):
         if self._ctx is None:
             return
         if self.shape == (1,) or len(self.shape) == 0 or allow_fill:
-            self._grad = self.__class__.ones(self.shape, requires_grad=False)
-            self._grad_shared = False
+            self._grad, self._grad_shared = self._seed_gradient()
         else:
             raise RuntimeError("Can only backpropagate from item tensors!")
         Gradients.backward(self._ctx, self._grad)
+
+    def _seed_gradient(self):
+        """(gradient the backward pass starts from, is-it-shared): ones(shape) (reference tensor.py:105).  A backend
+        may hand out a cached read-only constant for item tensors by returning shared=True."""
+        return self.__class__.ones(self.shape, requires_grad=False), False
 
     def add_grad(self, grad: "AbstractTensor") -> None:
         if not self._requires_grad:

@@ -133,23 +133,37 @@ struct AdamSegments {
 
 __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, AdamSegments seg, AdamScalars c,
-                                                      const int64_t* __restrict__ step, double b1, double b2) {
+                                                      int64_t* __restrict__ step, double b1, double b2, int advance) {
     const int j = blockIdx.y;
     const int64_t begin = seg.offsets[j], n = seg.offsets[j + 1] - begin;
     int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double t = double(step[0] * seg.nseg + j + 1);
-    c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
-    c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
-    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (; i < n; i += stride) adam_elem(p[begin + i], g[begin + i], m[begin + i], v[begin + i], c);
+    if (i < n) {
+        const double t = double(step[0] * seg.nseg + j + 1);
+        c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
+        c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
+        const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+        for (; i < n; i += stride) adam_elem(p[begin + i], g[begin + i], m[begin + i], v[begin + i], c);
+    }
+    if (advance) {
+        // the LAST workgroup to finish advances the step number (step[1] is an arrival ticket, zero between launches):
+        // every workgroup has read step[0] before it draws its ticket, so the write cannot race with a read
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+            const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ULL);
+            if (ticket == total - 1) {
+                step[1] = 0;
+                step[0] = step[0] + 1;
+            }
+        }
+    }
 }
 
 }  // namespace lg
 
 extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
-                                     double lr, double b1, double b2, double eps, const int64_t* step, double gscale,
-                                     int belief) {
+                                     double lr, double b1, double b2, double eps, int64_t* step, double gscale,
+                                     int belief, int advance) {
     LG_REQUIRE_INIT();
     LG_ARG(nseg >= 1 && nseg <= kMaxSegments, "lg_adam_multi_dev_f32: %d segments (1..%d supported)", nseg, kMaxSegments);
     LG_ARG(p && g && m && v && step && offsets, "lg_adam_multi_dev_f32: NULL pointer");
@@ -168,7 +182,7 @@ extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* 
     c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
     c.eps = float(eps); c.inv_bias1 = 0.f; c.inv_bias2 = 0.f; c.gscale = float(gscale); c.belief = belief;
     c.scale_grad = gscale != 1.0;
-    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid(longest), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2);
+    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid(longest), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2, advance);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -224,7 +224,8 @@ int lg_counter_add_i64(int64_t* counter, int64_t delta);
  * back to back, parameter j occupying [offsets[j], offsets[j+1]); its step number is
  * t = step[0] * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32.  `step` points at TWO int64:
  * step[0] the optimizer step, step[1] an arrival ticket that must be 0 between launches; with advance != 0
- * the last workgroup to finish increments step[0] (no separate counter launch). */
+ * the last workgroup to finish increments step[0] - one contended atomic per workgroup (~11 ns each), so only
+ * worth it for small grids; otherwise advance the counter with lg_counter_add_i64 (one tiny launch). */
 int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
                           double lr, double b1, double b2, double eps,
                           int64_t* step, double gscale, int belief, int advance);

@@ -100,7 +100,7 @@ class Adam(Optimizer):
         if self._flat is not None:
             flat_p, flat_m, flat_v, offsets = self._flat
             flat_p._fused_adam_multi_dev(self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2, self.eps,
-                                         self._step_counter, self.grad_scale, self.belief)   # also advances the counter
+                                         self._step_counter, self.grad_scale, self.belief)   # advances the device counter too
             self.t += n_params
             return
         for i, p in enumerate(self.parameters):

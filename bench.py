@@ -70,7 +70,7 @@ def main():
 
     def wall_max(seconds):
         """max over ranks (the slowest rank defines the job's time)"""
-        if world == 1:
+        if not multi:
             return seconds
         t = HipTensor.from_numpy(np.asarray([seconds], np.float32), requires_grad=False)
         comm.allreduce_max_(t)
@@ -162,7 +162,7 @@ def main():
     assert np.isfinite(final_loss), final_loss
     steps_per_s = world * args.steps / elapsed
     digest = dp.parameter_digest()
-    if world > 1:                                    # replicas must still be identical
+    if multi:                                        # replicas must still be identical
         d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
         comm.allreduce_max_(d)
         dmax, dmin = d.numpy()

@@ -3,4 +3,4 @@ The package name `hip` is what makes `AbstractTensor.hip()` appear (tensor.py me
 from .tensor import HipTensor, HipDevice, HipBuffer
 from .tensor import HipTensor as Tensor
 from .lib import HipError
-from .graph import HipGraph
+from .graph import HipGraph, GraphedStep

@@ -57,3 +57,40 @@ class HipGraph(object):
 
     def __del__(self):
         self.destroy()
+
+
+class GraphedStep(object):
+    """A training (or inference) step recorded once and replayed: `step = GraphedStep(fn, optimizers=[opt])`.
+
+    `fn()` must be a fixed-shape step over device tensors that performs no host transfer (see the rules in the
+    module docstring) and returns the tensor(s) to read afterwards (e.g. the loss).  The first `warmup` calls run
+    eagerly (they allocate optimizer state and fill the memory pool), the next call captures, every later call is
+    one `hipGraphLaunch`.  Optimizers passed in must use `device_step=True`; their host-side step count is kept
+    in line with the replays."""
+
+    def __init__(self, fn, optimizers=(), warmup: int = 2):
+        self._fn, self._opts, self._warmup = fn, tuple(optimizers), warmup
+        for o in self._opts:
+            assert getattr(o, "device_step", False), "GraphedStep needs optimizers created with device_step=True"
+        self._graph, self._result, self._calls = None, None, 0
+
+    def __call__(self):
+        self._calls += 1
+        if self._calls <= self._warmup:
+            return self._fn()
+        if self._graph is None:
+            before = [o.t for o in self._opts]
+            self._graph = HipGraph()
+            with self._graph.capture():
+                self._result = self._fn()
+            for o, t in zip(self._opts, before):
+                o.t = t                                   # the capture pass ran the python bookkeeping, not the kernels
+        self._graph.replay()
+        for o in self._opts:
+            o.on_graph_replay()
+        return self._result
+
+    def destroy(self):
+        if self._graph is not None:
+            self._graph.destroy()
+        self._graph = None

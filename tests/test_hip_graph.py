@@ -127,3 +127,16 @@ def test_graph_with_new_batches_through_async_upload(hip):
     np.testing.assert_allclose(got, eager, rtol=1e-6)
     for p, q in zip(model_e.parameters(), model_g.parameters()):
         np.testing.assert_allclose(q.numpy(), p.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_graphed_step_helper(hip):
+    from lightgrad_amd.autograd.hip import GraphedStep
+    g = load_golden("mlp_small_adabelief.npz")
+    model, opt, step, steps = build(hip, g, "adabelief", device_step=True)
+    graphed = GraphedStep(step, optimizers=[opt], warmup=2)
+    losses = [graphed().item() for _ in range(steps)]
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    assert opt.t == steps * 4
+    graphed.destroy()

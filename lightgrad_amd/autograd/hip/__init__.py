@@ -4,3 +4,4 @@ from .tensor import HipTensor, HipDevice, HipBuffer
 from .tensor import HipTensor as Tensor
 from .lib import HipError
 from .graph import HipGraph, GraphedStep
+from .profiler import HipProfiler

@@ -28,6 +28,13 @@ class Profiler(object):
             self._fwd_time[name] += time_delta
             self._fwd_calls[name] += 1
 
+    # hooks around every outermost tracked call (a device profiler records stream events here)
+    def on_enter(self, name, backward):
+        pass
+
+    def on_exit(self, name, backward):
+        pass
+
     def __enter__(self, *args):
         Profiler._active_profilers.append(self)
         return self
@@ -59,6 +66,9 @@ class Tracker(object):
 
     def __enter__(self, *args):
         Tracker._depth += 1
+        if self._charge:
+            for p in Profiler._active_profilers:
+                p.on_enter(self._name, self._backward)
         self._start = perf_counter()
 
     def __exit__(self, *args):
@@ -67,3 +77,4 @@ class Tracker(object):
             dt = perf_counter() - self._start
             for p in Profiler._active_profilers:
                 p.update(self._name, dt, self._backward)
+                p.on_exit(self._name, self._backward)

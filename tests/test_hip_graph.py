@@ -140,3 +140,20 @@ def test_graphed_step_helper(hip):
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
     assert opt.t == steps * 4
     graphed.destroy()
+
+
+def test_capture_without_warmup_allocates_inside_the_capture(hip):
+    """relaxed capture mode: pool misses fall through to hipMalloc while capturing; the blocks stay pinned to the graph"""
+    from lightgrad_amd.autograd.hip import HipGraph, HipDevice
+    a = hip.from_numpy(np.ones((1000, 1003), np.float32))
+    HipDevice.trim_pool()
+    before = HipDevice.pool_stats()["hip_malloc_calls"]
+    g = HipGraph()
+    with g.capture():
+        b = (a * 2.0 + 1.0).exp().sum()
+    assert HipDevice.pool_stats()["hip_malloc_calls"] > before
+    g.replay()
+    np.testing.assert_allclose(b.item(), 1000 * 1003 * np.exp(3.0), rtol=1e-5)
+    a.fill(0.0)                                   # new input values, same graph
+    g.replay()
+    np.testing.assert_allclose(b.item(), 1000 * 1003 * np.exp(1.0), rtol=1e-5)

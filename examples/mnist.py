@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--cnn", action="store_true", help="the convolutional model instead of the MLP")
+    ap.add_argument("--loss", choices=["mse", "ce"], default="mse", help="ce: the alternative the reference keeps commented out (mnist.py:57)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=1024)
     args = ap.parse_args()
@@ -104,7 +105,11 @@ def main():
         for i in range(args.steps):
             x, one_hot = batches[i % len(batches)]
             y = model(to_device(light.from_numpy(x)))
-            l = light.loss.mse(y, to_device(light.from_numpy(one_hot)))
+            if args.loss == "ce":
+                labels = light.from_numpy(one_hot.argmax(-1).astype(np.int64), requires_grad=False)
+                l = light.loss.cross_entropy(y, to_device(labels))
+            else:
+                l = light.loss.mse(y, to_device(light.from_numpy(one_hot)))
             optim.zero_grad()
             l.backward()
             optim.step()

@@ -255,6 +255,12 @@ int lg_gather_rows_f32(const float* table, const void* ids, int id_itemsize, flo
 int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, int id_itemsize, float* grad_table,
                             int64_t n_ids, int64_t row_len, int64_t table_rows);
 
+/* loss.cross_entropy (loss.py:14-24) for dense fp32 logits [rows, cols] and integer labels [rows] (int16/32/64):
+ *   nll[r] = -log(softmax(logits[r])[label[r]]);  dlogits[r][c] = (softmax(logits[r])[c] - [c == label[r]]) / rows
+ * the loss is mean(nll) (lg_reduce + one scalar multiply), its gradient dlogits * upstream. */
+int lg_cross_entropy_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                         int64_t rows, int64_t cols);
+
 /* library build info: "liblghip <version> gfx950 <build date>" */
 const char* lg_version(void);
 

@@ -890,6 +890,22 @@ def mse_forward(y, y_hat):
     return loss, err
 
 
+def cross_entropy_forward(y, labels):
+    """fused loss.cross_entropy forward for logits (N, C) and integer labels (N,): returns (mean nll of shape (),
+    dlogits = (softmax(y) - onehot) / N) from one row-wise pass (lg_cross_entropy_f32) + the mean over rows"""
+    _require_f32(y)
+    assert len(y._shape) == 2 and labels._shape == (y._shape[0],), \
+        "cross_entropy: logits %s and labels %s do not match" % (y._shape, labels._shape)
+    assert labels._dtype in (np.int16, np.int32, np.int64), "cross_entropy: labels must be int16/int32/int64"
+    y, labels = y.contiguous(), labels.contiguous()
+    n, c = y._shape
+    dlogits, nll = HipTensor.empty(y._shape), HipTensor.empty((n,))
+    _l.check(_l.lib().lg_cross_entropy_f32(y.ptr, labels.ptr, labels._dtype.itemsize, dlogits.ptr, nll.ptr, n, c))
+    total = _reduce(_l.RED_SUM, nll, (0,), False)
+    loss = _ew(_l.EW_MUL, (), [total, None], scalar=1.0 / n)
+    return loss, dlogits
+
+
 def adam_step_(p, g, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, gscale=1.0, belief=False):
     """in-place fused Adam/AdaBelief update of dense fp32 tensors (lg_adam_step_f32)"""
     _require_f32(p, g, m, v)

@@ -256,6 +256,11 @@ class HipTensor(AbstractTensor):
         from .ops import mse_forward
         return mse_forward(self, y_hat)
 
+    def _fused_cross_entropy(self, labels):
+        """optional loss hook (loss.cross_entropy): (loss, (softmax - onehot) / N) from one row-wise kernel"""
+        from .ops import cross_entropy_forward
+        return cross_entropy_forward(self, labels)
+
     def _fused_adam_multi_dev(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
         """self/grad/m/v are flat buckets holding len(offsets)-1 parameters: ONE launch updates them all"""
         for t in (self, grad, m, v):

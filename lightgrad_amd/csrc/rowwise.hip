@@ -135,6 +135,32 @@ __global__ void __launch_bounds__(256) layernorm_bwd(const float* __restrict__ g
     for (int64_t c = lane; c < cols; c += 64) dx[row * cols + c] = r * (gr[c] * w[c] - s1 - hr[c] * s2);
 }
 
+// ---- cross entropy of softmax(logits) against integer labels (reference loss.py:14-24) ------------------------
+// one wave per row: p = softmax(row); nll[row] = -log(p[label]); d[row][c] = (p[c] - [c == label]) / rows
+template <typename LabelT>
+__global__ void __launch_bounds__(256) cross_entropy_rows(const float* __restrict__ x, const LabelT* __restrict__ labels,
+                                                          float* __restrict__ dlogits, float* __restrict__ nll, int64_t rows,
+                                                          int64_t cols, float inv_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * cols;
+    float m = -INFINITY;
+    for (int64_t c = lane; c < cols; c += 64) { const float t = xr[c]; m = (t > m || t != t) ? t : m; }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) s += expf(xr[c] + (-m));
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    int64_t label = int64_t(labels[row]);
+    if (label < 0) label += cols;
+    for (int64_t c = lane; c < cols; c += 64) {
+        const float p = expf(xr[c] + (-m)) * inv;
+        dlogits[row * cols + c] = (c == label ? p - 1.0f : p) * inv_rows;
+        if (c == label) nll[row] = -logf(p);
+    }
+}
+
 // ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
 template <typename IdT>
 __global__ void __launch_bounds__(256) gather_rows(const float* __restrict__ table, const IdT* __restrict__ ids, float* __restrict__ out,
@@ -243,6 +269,26 @@ extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, i
         hipLaunchKernelGGL(scatter_add_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int32_t*>(ids), grad_table, n_ids, row_len, table_rows);
     else
         hipLaunchKernelGGL(scatter_add_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int64_t*>(ids), grad_table, n_ids, row_len, table_rows);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                                    int64_t rows, int64_t cols) {
+    LG_REQUIRE_INIT();
+    LG_ARG(label_itemsize == 2 || label_itemsize == 4 || label_itemsize == 8, "lg_cross_entropy_f32: labels must be int16/int32/int64");
+    LG_ARG(rows >= 0 && cols >= 1, "lg_cross_entropy_f32: bad shape");
+    if (rows == 0) return LG_OK;
+    LG_ARG(logits && labels && dlogits && nll, "lg_cross_entropy_f32: NULL pointer");
+    const dim3 grid(unsigned((rows + 3) / 4)), block(256);
+    const float inv_rows = float(1.0 / double(rows));
+    hipStream_t s = rt().stream;
+    if (label_itemsize == 2)
+        hipLaunchKernelGGL(cross_entropy_rows<int16_t>, grid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+    else if (label_itemsize == 4)
+        hipLaunchKernelGGL(cross_entropy_rows<int32_t>, grid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+    else
+        hipLaunchKernelGGL(cross_entropy_rows<int64_t>, grid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -2,7 +2,9 @@
 `mean((y - y_hat)^2) / 2`, gradient is `(y - y_hat) * out_grad` - WITHOUT the 1/N
 of the mean (reference quirk kept for parity; it makes the data-parallel
 gradient of a concatenated batch the SUM of per-rank gradients).
-`cross_entropy` (loss.py:14-24) needs fancy indexing and is out of scope."""
+`cross_entropy` restates loss.py:14-24 (softmax, pick the label's probability with an index pair, -log, mean; backward
+`(softmax - onehot) / N * out_grad`); the generic form needs fancy indexing (CpuTensor has it), HipTensor provides it
+as one fused kernel through the optional `_fused_cross_entropy` hook."""
 from .autograd import Function
 
 
@@ -23,3 +25,27 @@ class mse(Function):
     def backward(ctx, out_grad):
         err, = ctx.get_saved_tensors()
         return err * out_grad
+
+
+class cross_entropy(Function):
+    """ Cross Entropy Loss of softmax(y) against integer class labels y_hat of shape (N,) """
+
+    def forward(ctx, y, y_hat, axis: int = -1):
+        fused = getattr(y, "_fused_cross_entropy", None)
+        if fused is not None and len(y.shape) == 2 and axis in (-1, 1):
+            loss, dlogits = fused(y_hat)                   # dlogits = (softmax - onehot) / N
+            ctx.save_for_backward(dlogits, None, axis)
+            return loss
+        p = y.softmax(axis=axis)
+        ctx.save_for_backward(p, y_hat, axis)
+        n = y_hat.shape[0]
+        return -p[range(n), y_hat].log().mean()
+
+    def backward(ctx, out_grad):
+        p, y_hat, axis = ctx.get_saved_tensors()
+        if y_hat is None:
+            return p * out_grad
+        n = y_hat.shape[0]
+        p[range(n), y_hat] -= 1
+        p /= n
+        return p * out_grad

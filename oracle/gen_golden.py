@@ -179,6 +179,22 @@ def main():
     run_cnn("max_pool_2x3", lambda a: a.max_pool(kernel=(2, 3)), [img])
     np.savez_compressed(os.path.join(OUT, "cnn_ops.npz"), **cnn)
 
+    # ---------------------------------------------------------------- loss.cross_entropy (loss.py:14-24), labels int64/int32/int16
+    from lightgrad.loss import cross_entropy as ref_cross_entropy
+    ce = {}
+    rng3 = np.random.RandomState(99)
+    for name, (n, c), ldt in [("n8_c10_i64", (8, 10), np.int64), ("n5_c3_i32", (5, 3), np.int32),
+                              ("n33_c130_i16", (33, 130), np.int16), ("n1_c1000_i64", (1, 1000), np.int64)]:
+        logits = f32(rng3, -4, 4, (n, c))
+        labels = rng3.randint(0, c, size=n).astype(ldt)
+        up = f32(rng3, 0.5, 2, ())
+        y = T.from_numpy(logits.copy())
+        loss = ref_cross_entropy(y, T.from_numpy(labels, requires_grad=False))
+        (loss * T.from_numpy(up, requires_grad=False)).backward(allow_fill=True)
+        ce[name + "/logits"], ce[name + "/labels"], ce[name + "/w"] = logits, labels, up
+        ce[name + "/loss"], ce[name + "/grad"] = np.array(loss.numpy()), np.array(y.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "cross_entropy.npz"), **ce)
+
     # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
     # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
     # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.

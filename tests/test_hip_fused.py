@@ -78,3 +78,36 @@ def test_flat_buckets_single_launch_update_reproduces_reference(hip):
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
     assert opt.t == steps * 4
+
+
+@pytest.mark.parametrize("name", ["n8_c10_i64", "n5_c3_i32", "n33_c130_i16", "n1_c1000_i64"])
+def test_fused_cross_entropy_matches_reference_fixture(hip, name):
+    g = load_golden("cross_entropy.npz")
+    y = hip.from_numpy(g[name + "/logits"].copy())
+    labels = hip.from_numpy(g[name + "/labels"], requires_grad=False)
+    loss = light.loss.cross_entropy(y, labels)
+    (loss * hip.from_numpy(g[name + "/w"], requires_grad=False)).backward(allow_fill=True)
+    assert loss.shape == ()
+    np.testing.assert_allclose(loss.numpy(), g[name + "/loss"], rtol=1e-5)
+    np.testing.assert_allclose(y.grad.numpy(), g[name + "/grad"], rtol=1e-5, atol=1e-7)
+
+
+def test_fused_cross_entropy_full_size_and_views(hip):
+    """MNIST-sized logits, a transposed (non-dense) logits view, negative labels and the oracle at full size"""
+    rng = np.random.RandomState(5)
+    logits = rng.uniform(-6, 6, (1024, 10)).astype(np.float32)
+    labels = rng.randint(0, 10, 1024).astype(np.int64)
+    want_loss, want_grad = O.cross_entropy(logits, labels)
+    y = hip.from_numpy(logits)
+    loss = light.loss.cross_entropy(y, hip.from_numpy(labels, requires_grad=False))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_loss, rtol=1e-5)
+    np.testing.assert_allclose(y.grad.numpy(), want_grad, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(y.grad.numpy().sum(-1), 0, atol=1e-6)      # each row of softmax - onehot sums to zero
+    yt = hip.from_numpy(np.ascontiguousarray(logits.T))
+    loss_t = light.loss.cross_entropy(yt.transpose(1, 0), hip.from_numpy(labels - 10, requires_grad=False))
+    loss_t.backward()
+    np.testing.assert_allclose(loss_t.item(), want_loss, rtol=1e-5)
+    np.testing.assert_allclose(yt.grad.numpy(), want_grad.T, rtol=1e-5, atol=1e-8)
+    with pytest.raises(AssertionError):
+        light.loss.cross_entropy(y, hip.from_numpy(labels.astype(np.float32), requires_grad=False))

@@ -208,11 +208,23 @@ __global__ void __launch_bounds__(256) ew_gather(EwArgs a, IterDesc d) {
 // (tensor.py:118 fed by transpose.backward) and of contiguous() on a transposed view.
 // A 64x64 tile is staged through LDS so that both sides move in full 256-byte rows.
 constexpr int kTT = 64;
+
+// Tiles are walked along diagonals: consecutive workgroups differ in BOTH tile coordinates.  With a row-major walk
+// the workgroups in flight touch, on the transposed side, addresses that are equal modulo the leading dimension
+// (a power of two for the usual sizes), i.e. a handful of HBM channels (measured 2.0 TB/s at 8192^2).
+__device__ __forceinline__ void diagonal_tile(unsigned b, int tiles_r, int tiles_c, int64_t& r0, int64_t& c0) {
+    const unsigned tc = b % unsigned(tiles_c), j = b / unsigned(tiles_c);
+    const unsigned tr = (j + tc) % unsigned(tiles_r);
+    r0 = int64_t(tr) * kTT;
+    c0 = int64_t(tc) * kTT;
+}
+
 template <class Op>
-__global__ void __launch_bounds__(256) ew_transposed_tile(EwArgs a, IterDesc d, int tr_mask, int tiles_c) {
+__global__ void __launch_bounds__(256) ew_transposed_tile(EwArgs a, IterDesc d, int tr_mask, int tiles_r, int tiles_c) {
     __shared__ float tile[2][kTT][kTT + 1];   // at most two transposed inputs (host guarantees it)
     const int64_t R = d.shape[0], C = d.shape[1];
-    const int64_t r0 = int64_t(blockIdx.x / tiles_c) * kTT, c0 = int64_t(blockIdx.x % tiles_c) * kTT;
+    int64_t r0, c0;
+    diagonal_tile(blockIdx.x, tiles_r, tiles_c, r0, c0);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
     // stage column-contiguous inputs: walk them along their fast axis (rows of the logical matrix)
 #pragma unroll
@@ -240,6 +252,75 @@ __global__ void __launch_bounds__(256) ew_transposed_tile(EwArgs a, IterDesc d, 
             Op::apply(in, out);
 #pragma unroll
             for (int o = 0; o < Op::NOUT; ++o) a.out[o][r * d.stride[kOutSlot + o][0] + c * d.stride[kOutSlot + o][1]] = out[o];
+        }
+    }
+}
+
+// float4 form of the same tile: R % 4 == 0, C % 4 == 0, every operand 16-byte aligned with leading strides % 4 == 0.
+// Transposed inputs are read as float4 along their fast axis (16 lanes = one 256-byte run, 16 runs per pass) and
+// scattered into tile[r][c]; the compute pass reads 4 consecutive c per lane and moves float4 on the row-major side.
+template <class Op>
+__global__ void __launch_bounds__(256) ew_transposed_tile_v4(EwArgs a, IterDesc d, int tr_mask, int tiles_r, int tiles_c) {
+    __shared__ float tile[2][kTT][kTT + 1];
+    const int64_t R = d.shape[0], C = d.shape[1];
+    int64_t r0, c0;
+    diagonal_tile(blockIdx.x, tiles_r, tiles_c, r0, c0);
+    const int q = threadIdx.x & 15, line = threadIdx.x >> 4;   // 16 float4 per 64-wide run, 16 runs per pass
+#pragma unroll
+    for (int i = 0; i < Op::NIN; ++i) {
+        if (a.in[i] != nullptr && ((tr_mask >> i) & 1)) {
+            const int t = __popc(tr_mask & ((1 << i) - 1));
+            const int64_t ld = d.stride[kInSlot + i][1];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int cc = p * 16 + line;
+                const int64_t r = r0 + 4 * q, c = c0 + cc;
+                if (r < R && c < C) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.in[i] + c * ld + r);
+                    tile[t][4 * q + 0][cc] = v.x;
+                    tile[t][4 * q + 1][cc] = v.y;
+                    tile[t][4 * q + 2][cc] = v.z;
+                    tile[t][4 * q + 3][cc] = v.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int rr = p * 16 + line;
+        const int64_t r = r0 + rr, c = c0 + 4 * q;
+        if (r < R && c < C) {
+            float x[4][4];
+#pragma unroll
+            for (int i = 0; i < Op::NIN; ++i) {
+                if (a.in[i] == nullptr) {
+                    x[i][0] = x[i][1] = x[i][2] = x[i][3] = a.scalar;
+                } else if ((tr_mask >> i) & 1) {
+                    const int t = __popc(tr_mask & ((1 << i) - 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[i][k] = tile[t][rr][4 * q + k];
+                } else if (d.stride[kInSlot + i][1] != 0) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.in[i] + r * d.stride[kInSlot + i][0] + c);
+                    x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+                } else {
+                    const float v = a.in[i][r * d.stride[kInSlot + i][0]];
+                    x[i][0] = x[i][1] = x[i][2] = x[i][3] = v;
+                }
+            }
+            float y[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float in[4], out[2];
+#pragma unroll
+                for (int i = 0; i < Op::NIN; ++i) in[i] = x[i][k];
+                Op::apply(in, out);
+#pragma unroll
+                for (int o = 0; o < Op::NOUT; ++o) y[o][k] = out[o];
+            }
+#pragma unroll
+            for (int o = 0; o < Op::NOUT; ++o)
+                *reinterpret_cast<float4*>(a.out[o] + r * d.stride[kOutSlot + o][0] + c) = make_float4(y[o][0], y[o][1], y[o][2], y[o][3]);
         }
     }
 }
@@ -325,8 +406,20 @@ static int launch_ew(const EwArgs& args, const IterDesc& d) {
         if (ok && tr_mask != 0 && __builtin_popcount(tr_mask) <= 2) {
             int64_t tiles_r = (d.shape[0] + kTT - 1) / kTT, tiles_c = (d.shape[1] + kTT - 1) / kTT;
             if (tiles_r * tiles_c < (int64_t(1) << 31)) {
-                hipLaunchKernelGGL((ew_transposed_tile<Op>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
-                                   tr_mask, int(tiles_c));
+                bool v4 = d.shape[0] % 4 == 0 && d.shape[1] % 4 == 0;
+                for (int o = 0; o < nslots_out && v4; ++o) v4 = aligned16(args.out[o]) && d.stride[kOutSlot + o][0] % 4 == 0;
+                for (int i = 0; i < nslots_in && v4; ++i) {
+                    if (!args.in[i]) continue;
+                    const int64_t s0 = d.stride[kInSlot + i][0], s1 = d.stride[kInSlot + i][1];
+                    if ((tr_mask >> i) & 1) v4 = aligned16(args.in[i]) && s1 % 4 == 0;
+                    else if (s1 == 1) v4 = aligned16(args.in[i]) && s0 % 4 == 0;
+                }
+                if (v4)
+                    hipLaunchKernelGGL((ew_transposed_tile_v4<Op>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
+                                       tr_mask, int(tiles_r), int(tiles_c));
+                else
+                    hipLaunchKernelGGL((ew_transposed_tile<Op>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
+                                       tr_mask, int(tiles_r), int(tiles_c));
                 return LG_OK;
             }
         }

@@ -247,6 +247,35 @@ def test_elementwise_full_size(hip):
     np.testing.assert_array_equal((tc.reshape(-1)[3:] * 2.0).numpy(), c.reshape(-1)[3:] * 2.0)
 
 
+@pytest.mark.parametrize("shape", [(128, 192), (64, 64), (68, 132), (130, 67), (17, 16), (200, 8192), (4100, 36)])
+def test_transposed_operand_tiles(hip, shape):
+    """both forms of the LDS-transposing tile (float4 when every extent/stride is a multiple of 4, scalar otherwise):
+    one or two transposed inputs, a row-contiguous and a row-broadcast input next to them, two outputs, in place,
+    and views that break the 16-byte alignment; shape/index work, so exact"""
+    rng = np.random.RandomState(3)
+    r, c = shape
+    a = rng.uniform(-1, 1, (r, c)).astype(np.float32)
+    bt = rng.uniform(-1, 1, (c, r)).astype(np.float32)
+    ct = rng.uniform(-1, 1, (c, r)).astype(np.float32)
+    col = rng.uniform(-1, 1, (r, 1)).astype(np.float32)
+    ta, tbt, tct, tcol = (hip.from_numpy(x) for x in (a, bt, ct, col))
+    np.testing.assert_array_equal(tbt.transpose(1, 0).contiguous().numpy(), bt.T)
+    np.testing.assert_array_equal((ta + tbt.transpose(1, 0)).numpy(), a + bt.T)
+    np.testing.assert_array_equal((tbt.transpose(1, 0) * tct.transpose(1, 0)).numpy(), bt.T * ct.T)
+    np.testing.assert_array_equal((tbt.transpose(1, 0) * tcol).numpy(), bt.T * col)
+    y = ta * tbt.transpose(1, 0)                                    # mul backward writes two outputs from (a, b^T, g^T)
+    (y * tct.transpose(1, 0)).backward(allow_fill=True)
+    np.testing.assert_array_equal(ta.grad.numpy(), ct.T * bt.T)
+    np.testing.assert_array_equal(tbt.grad.numpy(), (a * ct.T).T)
+    with light.no_grad():
+        acc = hip.from_numpy(a.copy())
+        acc += tbt.transpose(1, 0)
+    np.testing.assert_array_equal(acc.numpy(), a + bt.T)
+    if r > 20 and c > 20:                                           # offset views: no operand is 16-byte aligned any more
+        np.testing.assert_array_equal((ta[1:, 1:] + tbt.transpose(1, 0)[1:, 1:]).numpy(), a[1:, 1:] + bt.T[1:, 1:])
+        np.testing.assert_array_equal((ta[:-4, 4:] + tbt[4:, :-4].transpose(1, 0)).numpy(), a[:-4, 4:] + bt[4:, :-4].T)
+
+
 def test_reductions_full_size(hip):
     rng = np.random.RandomState(1)
     n = 4096

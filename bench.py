@@ -100,7 +100,8 @@ def main():
     if use_graph:
         dp.attach(opt)                               # flat buckets: zero_grad = one fill, update = one launch
     rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
-    x = HipTensor.from_numpy(rng.uniform(0, 1, (1024, 784)).astype(np.float32))
+    x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
+    x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
     labels = rng.randint(0, 10, 1024)
     onehot_np = np.zeros((1024, 10), np.float32)
     onehot_np[np.arange(1024), labels] = 1
@@ -167,6 +168,34 @@ def main():
         comm.allreduce_max_(d)
         dmax, dmin = d.numpy()
         assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
+
+    # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
+    # computes and drops, is then not computed at all.  Reported next to `value`, never as `value`.
+    data_input_steps_per_s = None
+    if use_graph and not multi:
+        x_data = HipTensor.from_numpy(x_np, requires_grad=False)
+
+        def data_step():
+            loss = light.loss.mse(model(x_data), onehot)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(2):
+            data_step()
+        g_data = HipGraph()
+        with g_data.capture():
+            data_step()
+        opt.t -= n_params
+        for _ in range(args.warmup):
+            g_data.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g_data.replay()
+        fence()
+        data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
+        opt.on_graph_replay(args.warmup + args.steps)
 
     # ------------------------------------------------------------------ 4096^2 matmul forward + backward
     np.random.seed(0)
@@ -340,10 +369,12 @@ def main():
             "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
                        "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
                        "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
+                       "input_requires_grad": True,
                        "dispatch": "hipGraph replay (python tape captured once)" if use_graph else "eager python tape",
                        "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "final_loss": round(final_loss, 6),
             "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),
+            "mlp_steps_per_sec_batch_as_data": None if data_input_steps_per_s is None else round(data_input_steps_per_s, 2),
             "secondary": {"metric": "matmul4096_fwd_bwd_tflops", "value": round(mm_tflops, 2), "unit": "TFLOP/s",
                           "ms_per_iter": round(1e3 * mm_elapsed / args.matmul_iters, 4), "iters": args.matmul_iters,
                           "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),

@@ -54,7 +54,13 @@ class _FunctionType(type):
             out = cls._apply(f, args, kwargs)
         assert isinstance(out, AbstractTensor)
         if Gradients._disable_depth == 0:
-            out._set_ctx(f)
+            if f.parent_tensors:
+                out._set_ctx(f)
+            else:
+                # extension of the reference (func.py:25-28 attaches the node regardless): nothing upstream wants a
+                # gradient (inputs created with requires_grad=False), so the result is a constant of the tape as well -
+                # no node, and backward ops further down skip the gradient for it (e.g. dx of the first Linear)
+                out._requires_grad = False
         return out
 
 

@@ -236,3 +236,28 @@ def test_module_parameter_plumbing():
     m2.map_parameters(lambda p: CpuTensor.from_numpy(p.numpy() * 0))
     assert all(np.all(p.numpy() == 0) for p in m2.parameters())
     assert gradcheck(lambda x: m(x), CpuTensor.uniform(-1, 1, (2, 4)))
+
+
+def test_constants_of_the_tape_do_not_grow_nodes():
+    """extension: an op whose inputs all have requires_grad=False returns a constant (no node, requires_grad False),
+    so data tensors cost no backward work; every gradient that IS wanted is unchanged"""
+    rng = np.random.RandomState(0)
+    x_np = rng.uniform(0, 1, (6, 2, 4)).astype(np.float32)
+    target = rng.uniform(0, 1, (6, 3)).astype(np.float32)
+    grads = []
+    for needs in (True, False):
+        np.random.seed(3)
+        model = light.nn.Linear(8, 3)
+        x = CpuTensor.from_numpy(x_np, requires_grad=needs)
+        flat = x.reshape(-1, 8)
+        assert flat.requires_grad == needs and (flat.ctx is not None) == needs
+        loss = light.loss.mse(model(flat), CpuTensor.from_numpy(target, requires_grad=False))
+        loss.backward()
+        assert (x.grad is not None) == needs
+        grads.append([p.grad.numpy().copy() for p in model.parameters()])
+    for a, b in zip(*grads):
+        np.testing.assert_array_equal(a, b)
+    c = CpuTensor.from_numpy(x_np, requires_grad=False) * 2.0 + 1.0
+    assert c.ctx is None and not c.requires_grad
+    c.backward(allow_fill=True)                                    # nothing to do, like backward on a leaf
+    assert c.grad is None

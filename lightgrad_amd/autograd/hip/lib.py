@@ -10,7 +10,7 @@ import os
 from ctypes import c_int, c_int64, c_uint32, c_uint64, c_size_t, c_float, c_double, c_void_p, c_char_p, POINTER
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(_PKG_DIR, "liblghip.so")
+LIB_PATH = os.environ.get("LIGHTGRAD_HIP_LIB") or os.path.join(_PKG_DIR, "liblghip.so")   # override: kernel experiments
 COMM_LIB_PATH = os.path.join(_PKG_DIR, "liblghip_comm.so")
 
 # lg_ew op ids (lghip.h: lg_ew_op_t)

@@ -17,6 +17,10 @@ struct Runtime {
     int         device = -1;
     hipStream_t stream = nullptr;
     int         compute_units = 0;
+    // arrival counters of the split-K GEMM (one per output tile): zero between launches - the workgroup that
+    // arrives last at a tile folds the partial products and resets the counter
+    int*        gemm_tickets = nullptr;
+    int         n_gemm_tickets = 0;
 };
 Runtime& rt();
 

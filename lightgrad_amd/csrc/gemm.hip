@@ -22,10 +22,18 @@
 // pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace lg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef LG_SMALL_PD
+#define LG_SMALL_PD 2
+#endif
+constexpr int kSmallTilePrefetch = LG_SMALL_PD;
 
 struct GemmArgs {
     const float* A;
@@ -39,11 +47,13 @@ struct GemmArgs {
     int     accumulate;
     const float* bias;      // optional [N]: added to every row of the product (nn.Linear's `+ b`, nn.py:96)
     // split-K: slice s of k_slices handles k in [s*k_per_slice, min(K, (s+1)*k_per_slice)) and writes its partial
-    // product to W + (batch*k_slices + s)*M*N (dense, ld = N); splitk_combine sums the slices in a fixed order
+    // tile to the workspace W (accumulator layout, see the kernel); the workgroup that arrives LAST at a tile
+    // (per-tile ticket) sums the slices in index order - deterministic - and runs the epilogue
     int     group_m;        // tile rows walked before moving to the next tile column
     int     k_slices;
     int64_t k_per_slice;    // multiple of BK
     float*  W;
+    int*    tickets;        // one per (batch, tile), zero on entry and on exit
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -55,7 +65,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + pos;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB>
+// the 256x256 tile never splits K (its launches have >= 256 tiles or lose to smaller tiles in the cost model); leaving
+// the fold out of that instantiation keeps its main loop free of spills
+template <int BM, int BN> constexpr bool kCanSplitK = BM * BN < 256 * 256;
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD>
 __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -93,113 +107,114 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
     const float* __restrict__ A = g.A + int64_t(batch) * g.sA;
     const float* __restrict__ B = g.B + int64_t(batch) * g.sB;
-    float* __restrict__ C = g.k_slices > 1 ? g.W + int64_t(bs) * g.M * g.N : g.C + int64_t(batch) * g.sC;
-    const int64_t ldc = g.k_slices > 1 ? g.N : g.ldc;
-    const int accumulate = g.k_slices > 1 ? 0 : g.accumulate;
-    const float* __restrict__ bias = g.k_slices > 1 ? nullptr : g.bias;   // split-K: the combine pass adds it once
+    float* __restrict__ C = g.C + int64_t(batch) * g.sC;
+    const int64_t ldc = g.ldc;
+    const int accumulate = g.accumulate;
+    const float* __restrict__ bias = g.bias;
     const int64_t k_begin = int64_t(slice) * g.k_per_slice;
     const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
 
-    float ra[A_ELEMS], rb[B_ELEMS];   // staging registers
+    // staging registers: a ring of PD K-tiles in flight between global memory and LDS (PD = 1: the tile fetched at the
+    // top of an iteration is written to LDS in its middle; small tiles have too few MFMAs per K-tile to cover the
+    // load latency that way and run PD = 2..3)
+    using StageA = std::conditional_t<VA, f32x4, float>;
+    using StageB = std::conditional_t<VB, f32x4, float>;
+    constexpr int A_CHUNKS = VA ? A_ELEMS / 4 : A_ELEMS, B_CHUNKS = VB ? B_ELEMS / 4 : B_ELEMS;
+    constexpr int NL = A_CHUNKS + B_CHUNKS;          // loads per thread and K-tile
+    static_assert((PD - 1) * NL + NL <= 63, "vmcnt is a 6-bit counter");
+    StageA ra_ring[PD][A_CHUNKS];
+    StageB rb_ring[PD][B_CHUNKS];
 
-    auto load_tile = [&](int64_t k0) {
-        if constexpr (VA) {
+    // Global -> register staging through buffer loads: the descriptor starts at the K-tile's first element (wave-uniform),
+    // the per-thread byte offsets are loop invariant, and every predicate (row / column beyond the matrix, k beyond the
+    // slice) turns the offset into one past the descriptor's range, for which the hardware returns 0 - no branches and
+    // no zero-fill moves in the K loop.
+    constexpr unsigned OOB = 0x80000000u;            // == num_records
+    unsigned offA[A_CHUNKS], offB[B_CHUNKS];
+    int kcA[A_CHUNKS], kcB[B_CHUNKS];                // k coordinate of the chunk inside its K-tile
 #pragma unroll
-            for (int i = 0; i < A_ELEMS / 4; ++i) {
-                const int f = tid + i * NT;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (AKC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    if (m0 + row < g.M && k0 + kq * 4 < k_end)
-                        v = *reinterpret_cast<const float4*>(A + (m0 + row) * g.lda + k0 + kq * 4);
-                } else {
-                    const int kk = f / (BM / 4), mq = f % (BM / 4);
-                    if (k0 + kk < k_end && m0 + mq * 4 < g.M)
-                        v = *reinterpret_cast<const float4*>(A + (k0 + kk) * g.lda + m0 + mq * 4);
-                }
-                ra[4 * i] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
-            }
-        } else {
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        const int f = tid + i * NT;
+        int row, kk;                                  // row: index along M inside the tile, kk: index along K
+        if constexpr (VA) { if constexpr (AKC) { row = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BM / 4); row = (f % (BM / 4)) * 4; } }
+        else              { if constexpr (AKC) { row = f / BK; kk = f % BK; } else { kk = f / BM; row = f % BM; } }
+        kcA[i] = kk;
+        const int64_t bytes = AKC ? (int64_t(row) * g.lda + kk) * 4 : (int64_t(kk) * g.lda + row) * 4;
+        offA[i] = (m0 + row < g.M) ? unsigned(bytes) : OOB;
+    }
 #pragma unroll
-            for (int i = 0; i < A_ELEMS; ++i) {
-                const int e = tid + i * NT;
-                float v = 0.f;
-                if constexpr (AKC) {
-                    const int row = e / BK, kk = e % BK;
-                    if (m0 + row < g.M && k0 + kk < k_end) v = A[(m0 + row) * g.lda + k0 + kk];
-                } else {
-                    const int kk = e / BM, mm = e % BM;
-                    if (k0 + kk < k_end && m0 + mm < g.M) v = A[(k0 + kk) * g.lda + m0 + mm];
-                }
-                ra[i] = v;
-            }
+    for (int i = 0; i < B_CHUNKS; ++i) {
+        const int f = tid + i * NT;
+        int col, kk;
+        if constexpr (VB) { if constexpr (BKC) { col = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BN / 4); col = (f % (BN / 4)) * 4; } }
+        else              { if constexpr (BKC) { col = f / BK; kk = f % BK; } else { kk = f / BN; col = f % BN; } }
+        kcB[i] = kk;
+        const int64_t bytes = BKC ? (int64_t(col) * g.ldb + kk) * 4 : (int64_t(kk) * g.ldb + col) * 4;
+        offB[i] = (n0 + col < g.N) ? unsigned(bytes) : OOB;
+    }
+    const float* const Atile0 = AKC ? A + m0 * g.lda : A + m0;      // + k0 (AKC) / + k0 * lda per K-tile
+    const float* const Btile0 = BKC ? B + n0 * g.ldb : B + n0;
+
+    // The loads are inline asm so that the K loop can keep PD tiles in flight: hipcc's own wait insertion is
+    // conservative across the loop back-edge (it drains every outstanding load before the first LDS write).  The
+    // destination registers are NOT protected until wait_tile() below has run for that ring slot.
+    auto descriptor = [](const float* base) {
+        const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+        u32x4 d;
+        d[0] = unsigned(p); d[1] = unsigned(p >> 32) & 0xffffu; d[2] = OOB; d[3] = 0x00020000u;
+        return d;
+    };
+    auto load_tile = [&](int64_t k0, int slot) {
+        const int krem = int(k_end - k0 < BK ? k_end - k0 : BK);     // k values of this tile inside the slice
+        const u32x4 da = descriptor(AKC ? Atile0 + k0 : Atile0 + k0 * g.lda);
+        const u32x4 db = descriptor(BKC ? Btile0 + k0 : Btile0 + k0 * g.ldb);
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const unsigned off = kcA[i] < krem ? offA[i] : OOB;
+            if constexpr (VA) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra_ring[slot][i]) : "v"(off), "s"(da));
+            else              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(ra_ring[slot][i]) : "v"(off), "s"(da));
         }
-        if constexpr (VB) {
 #pragma unroll
-            for (int i = 0; i < B_ELEMS / 4; ++i) {
-                const int f = tid + i * NT;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (BKC) {
-                    const int row = f / (BK / 4), kq = f % (BK / 4);
-                    if (n0 + row < g.N && k0 + kq * 4 < k_end)
-                        v = *reinterpret_cast<const float4*>(B + (n0 + row) * g.ldb + k0 + kq * 4);
-                } else {
-                    const int kk = f / (BN / 4), nq = f % (BN / 4);
-                    if (k0 + kk < k_end && n0 + nq * 4 < g.N)
-                        v = *reinterpret_cast<const float4*>(B + (k0 + kk) * g.ldb + n0 + nq * 4);
-                }
-                rb[4 * i] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_ELEMS; ++i) {
-                const int e = tid + i * NT;
-                float v = 0.f;
-                if constexpr (BKC) {
-                    const int row = e / BK, kk = e % BK;
-                    if (n0 + row < g.N && k0 + kk < k_end) v = B[(n0 + row) * g.ldb + k0 + kk];
-                } else {
-                    const int kk = e / BN, nn = e % BN;
-                    if (k0 + kk < k_end && n0 + nn < g.N) v = B[(k0 + kk) * g.ldb + n0 + nn];
-                }
-                rb[i] = v;
-            }
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const unsigned off = kcB[i] < krem ? offB[i] : OOB;
+            if constexpr (VB) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb_ring[slot][i]) : "v"(off), "s"(db));
+            else              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rb_ring[slot][i]) : "v"(off), "s"(db));
         }
     };
+    // wait until the loads of ring slot `slot` have landed, given that `younger` tiles were requested after it
+    auto wait_tile = [&](int slot, int younger) {
+        if (PD >= 3 && younger >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PD >= 3 ? 2 * NL : 0) : "memory");
+        else if (PD >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PD >= 2 ? NL : 0) : "memory");
+        else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) asm volatile("" : "+v"(ra_ring[slot][i]));
+#pragma unroll
+        for (int i = 0; i < B_CHUNKS; ++i) asm volatile("" : "+v"(rb_ring[slot][i]));
+    };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, int slot) {
         float* a = lds + buf * BUF;
         float* b = lds + buf * BUF + A_TILE;
-        if constexpr (VA) {
 #pragma unroll
-            for (int i = 0; i < A_ELEMS / 4; ++i) {
-                const int f = tid + i * NT;
-                const float4 v = make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
-                if constexpr (AKC) *reinterpret_cast<float4*>(a + (f / (BK / 4)) * A_PITCH + (f % (BK / 4)) * 4) = v;
-                else               *reinterpret_cast<float4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_ELEMS; ++i) {
-                const int e = tid + i * NT;
-                if constexpr (AKC) a[(e / BK) * A_PITCH + (e % BK)] = ra[i];
-                else               a[(e / BM) * A_PITCH + (e % BM)] = ra[i];
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int f = tid + i * NT;
+            if constexpr (VA) {
+                if constexpr (AKC) *reinterpret_cast<f32x4*>(a + (f / (BK / 4)) * A_PITCH + (f % (BK / 4)) * 4) = ra_ring[slot][i];
+                else               *reinterpret_cast<f32x4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = ra_ring[slot][i];
+            } else {
+                if constexpr (AKC) a[(f / BK) * A_PITCH + (f % BK)] = ra_ring[slot][i];
+                else               a[(f / BM) * A_PITCH + (f % BM)] = ra_ring[slot][i];
             }
         }
-        if constexpr (VB) {
 #pragma unroll
-            for (int i = 0; i < B_ELEMS / 4; ++i) {
-                const int f = tid + i * NT;
-                const float4 v = make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
-                if constexpr (BKC) *reinterpret_cast<float4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = v;
-                else               *reinterpret_cast<float4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_ELEMS; ++i) {
-                const int e = tid + i * NT;
-                if constexpr (BKC) b[(e / BK) * B_PITCH + (e % BK)] = rb[i];
-                else               b[(e / BN) * B_PITCH + (e % BN)] = rb[i];
+        for (int i = 0; i < B_CHUNKS; ++i) {
+            const int f = tid + i * NT;
+            if constexpr (VB) {
+                if constexpr (BKC) *reinterpret_cast<f32x4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = rb_ring[slot][i];
+                else               *reinterpret_cast<f32x4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = rb_ring[slot][i];
+            } else {
+                if constexpr (BKC) b[(f / BK) * B_PITCH + (f % BK)] = rb_ring[slot][i];
+                else               b[(f / BN) * B_PITCH + (f % BN)] = rb_ring[slot][i];
             }
         }
     };
@@ -249,17 +264,104 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     };
 
     const int64_t nkt = (k_end - k_begin + BK - 1) / BK;
-    load_tile(k_begin);
-    store_tile(0);
+    // tile j waits in ring slot j % PD; tiles 0 .. PD-1 are requested up front
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+        if (u < nkt) load_tile(k_begin + u * BK, u);
+    {
+        const int64_t younger = nkt - 1 < PD - 1 ? nkt - 1 : PD - 1;
+        wait_tile(0, int(younger));
+    }
+    store_tile(0, 0);
     __syncthreads();
-    for (int64_t kt = 0; kt < nkt; ++kt) {
-        const int cur = int(kt & 1);
-        const bool more = kt + 1 < nkt;
-        if (more) load_tile(k_begin + (kt + 1) * BK);      // in flight during the MFMAs below
-        compute_tile(cur, 0, BK / 2);
-        if (more) store_tile(cur ^ 1);           // ds_writes issue in the shadow of the second half's MFMAs
-        compute_tile(cur, BK / 2, BK);
+    for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int64_t kt = kt0 + u;
+            if (kt < nkt) {
+                const int cur = int(kt & 1);
+                // PD == 1: tile kt+1 is requested here and written to LDS in the middle of this iteration.
+                // PD  > 1: slot u (tile kt, in LDS since the last iteration) is refilled with tile kt + PD below, after
+                //          the LDS write of tile kt+1 - whose loads were requested PD-1 iterations ago.
+                if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
+                compute_tile(cur, 0, BK / 2);
+                if (kt + 1 < nkt) {
+                    int64_t younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
+                    if (younger > PD - 2) younger = PD - 2;
+                    wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
+                    store_tile(cur ^ 1, (u + 1) % PD);                // ds_writes issue in the shadow of the second half's MFMAs
+                }
+                if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
+                compute_tile(cur, BK / 2, BK);
+                __syncthreads();
+            }
+        }
+    }
+
+    if constexpr (kCanSplitK<BM, BN>) if (g.k_slices > 1) {
+        // split-K, folded inside the launch (cdna_hip_programming.md, in-launch split-K recipe, write-through form).
+        // Partial tiles go to the workspace in ACCUMULATOR layout - 16-byte piece ((i*TN + j)*4 + q) of thread tid at
+        // byte (((i*TN + j)*4 + q)*NT + tid)*16 of the (batch, slice, tile) slab - so stores and the fold move 1 KiB per
+        // wave instruction.  The slices of a tile run on different XCDs whose L2s are not coherent: slabs are stored
+        // write-through (sc1) and drained, ONE lane takes an agent-scope ticket, and the workgroup that arrives last
+        // reads every slab with sc1 loads (never served from a stale line), sums them in slice order - the same
+        // order in every run, so results are bit-reproducible - and runs the epilogue.  The ticket is reset for the
+        // next launch by that workgroup.
+        constexpr int SC1 = 16;                                   // aux bit of the raw buffer builtins
+        constexpr int TILE_BYTES = BM * BN * 4;
+        char* slab0 = reinterpret_cast<char*>(g.W) + (int64_t(batch) * g.k_slices * per_batch + t) * int64_t(TILE_BYTES);
+        const int64_t slice_stride = int64_t(per_batch) * TILE_BYTES;
+        {
+            const auto mine = __builtin_amdgcn_make_buffer_rsrc(slab0 + slice * slice_stride, 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        u32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * q + e]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, mine, (((i * TN + j) * 4 + q) * NT + tid) * 16, 0, SC1);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
         __syncthreads();
+        int* arrived_last = reinterpret_cast<int*>(lds);          // the staging buffers are free after the K loop's last barrier
+        if (tid == 0) {
+            int* ticket = g.tickets + batch * per_batch + t;
+            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = order == g.k_slices - 1;
+            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *arrived_last = last;
+        }
+        __syncthreads();
+        if (!*arrived_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the slab loads below the ticket
+        constexpr int CH = TM * TN >= 4 ? 1 : (TM * TN == 2 ? 2 : 4);     // slices whose loads are in flight together
+        for (int s0 = 0; s0 < g.k_slices; s0 += CH) {
+            u32x4 v[CH][TM * TN * 4];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int sl = s0 + c < g.k_slices ? s0 + c : s0;
+                const auto src = __builtin_amdgcn_make_buffer_rsrc(slab0 + sl * slice_stride, 0, TILE_BYTES, 0x00020000);
+#pragma unroll
+                for (int f = 0; f < TM * TN * 4; ++f) v[c][f] = __builtin_amdgcn_raw_buffer_load_b128(src, (f * NT + tid) * 16, 0, SC1);
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const bool live = s0 + c < g.k_slices, first = s0 + c == 0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const float w = __uint_as_float(v[c][(i * TN + j) * 4 + e / 4][e % 4]);
+                            acc[i][j][e] = first ? w : (live ? acc[i][j][e] + w : acc[i][j][e]);
+                        }
+            }
+        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -292,32 +394,15 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     }
 }
 
-// C[b][m][n] (+)= sum_s W[b][s][m][n], slices added in index order (deterministic)
-__global__ void __launch_bounds__(256) splitk_combine(const float* __restrict__ W, float* __restrict__ C, int64_t M, int64_t N,
-                                                      int64_t ldc, int64_t sC, int slices, int64_t total, int accumulate,
-                                                      const float* __restrict__ bias) {
-    const int64_t mn = M * N;
-    int64_t stride = int64_t(gridDim.x) * blockDim.x;
-    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t b = e / mn, r = e - b * mn;
-        const int64_t m = r / N, n = r - m * N;
-        const float* w = W + b * slices * mn + r;
-        float acc = w[0];
-        for (int s = 1; s < slices; ++s) acc += w[int64_t(s) * mn];
-        if (bias) acc += bias[n];
-        float* c = C + b * sC + m * ldc + n;
-        *c = accumulate ? *c + acc : acc;
-    }
-}
-
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
 static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     dim3 grid(g.nwg), block(WM * WN * 64);
     hipStream_t s = rt().stream;
-    if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true>), grid, block, 0, s, g);
-    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false>), grid, block, 0, s, g);
-    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true>), grid, block, 0, s, g);
-    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false>), grid, block, 0, s, g);
+    constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 1;
+    if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD>), grid, block, 0, s, g);
+    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, PD>), grid, block, 0, s, g);
+    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, PD>), grid, block, 0, s, g);
+    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, PD>), grid, block, 0, s, g);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -328,32 +413,36 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n * batch;
     // split-K when the tile grid alone cannot fill 256 CUs: aim at >= 512 workgroups, keep >= 2 K-tiles per slice
     int64_t slices = 1;
-    if (tiles < 256 && g.K >= 4 * BK) {
+    if (kCanSplitK<BM, BN> && tiles < 256 && g.K >= 4 * BK) {
         slices = (512 + tiles - 1) / tiles;
         const int64_t max_slices = g.K / (2 * BK);
         if (slices > max_slices) slices = max_slices;
         if (slices > 64) slices = 64;
         if (slices < 1) slices = 1;
     }
+    static const char* slices_env = getenv("LG_GEMM_SLICES");      // experiments only
+    if (kCanSplitK<BM, BN> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);
     g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;
     slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
     g.k_slices = int(slices);
     g.nwg = int(tiles * slices);
     g.W = nullptr;
+    g.tickets = rt().gemm_tickets;
+    if (slices > 1 && tiles > rt().n_gemm_tickets) {       // more tiles than tickets: plenty of workgroups anyway
+        slices = 1;
+        g.k_per_slice = (g.K + BK - 1) / BK * BK;
+        g.k_slices = 1;
+        g.nwg = int(tiles);
+    }
     if (slices > 1) {
-        int rc = lg_malloc(reinterpret_cast<void**>(&g.W), size_t(batch * slices * g.M * g.N) * sizeof(float));
+        int rc = lg_malloc(reinterpret_cast<void**>(&g.W), size_t(tiles * slices) * BM * BN * sizeof(float));
         if (rc != LG_OK) return rc;
     }
     if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true>(g, va, vb);
     else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false>(g, va, vb);
     else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true>(g, va, vb);
     else            launch_layout<BM, BN, BK, WM, WN, false, false>(g, va, vb);
-    if (slices > 1) {
-        const int64_t total = batch * g.M * g.N;
-        hipLaunchKernelGGL(splitk_combine, dim3(stream_grid(total)), dim3(256), 0, rt().stream, g.W, g.C, g.M, g.N, g.ldc, g.sC,
-                           g.k_slices, total, g.accumulate, g.bias);
-        return lg_free(g.W);     // stream-ordered: reused only by later launches
-    }
+    if (slices > 1) return lg_free(g.W);     // stream-ordered: reused only by later launches
     return LG_OK;
 }
 
@@ -382,6 +471,9 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
         return lg_fill_strided(4, 3, shape, C, st, 0);
     }
 
+    // operand tiles are addressed with 32-bit byte offsets from a per-tile descriptor base (at most 256 rows / k-steps)
+    LG_ARG(lda < (int64_t(1) << 20) && ldb < (int64_t(1) << 20), "lg_gemm_f32: leading dimension >= 2^20 elements (lda=%lld ldb=%lld)",
+           (long long)lda, (long long)ldb);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
     g.M = M; g.N = N; g.K = K;

@@ -123,6 +123,9 @@ int lg_init(int device) {
     hipDeviceProp_t prop;
     LG_HIP(hipGetDeviceProperties(&prop, device));
     R.compute_units = prop.multiProcessorCount;
+    R.n_gemm_tickets = 1 << 16;
+    LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.gemm_tickets), size_t(R.n_gemm_tickets) * sizeof(int)));
+    LG_HIP(hipMemset(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int)));
     R.device = device;
     R.ready = true;
     return LG_OK;

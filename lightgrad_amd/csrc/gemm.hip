@@ -274,26 +274,87 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     }
     store_tile(0, 0);
     __syncthreads();
-    for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+    if constexpr (TM * TN == 1) {
+        // One accumulator per wave (small tiles: often ONE such wave per SIMD, nothing else to hide latency behind):
+        // the fragments of the next half K-tile are fetched from LDS while the MFMAs of the current half run.  The
+        // barrier sits between the halves: before it every wave has read ALL of tile kt and written its share of tile
+        // kt+1, after it the first-half fragments of tile kt+1 are fetched under the second half's MFMAs.
+        constexpr int HG = BK / 16;                  // k-groups of 8 per half tile
+        float fa[2][HG][4], fb[2][HG][4];
+        auto read_half = [&](int buf, int half, int slot) {
+            const float* a = lds + buf * BUF + (AKC ? (wm * 32 + r) * A_PITCH + 4 * h : (4 * h) * A_PITCH + wm * 32 + r);
+            const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * 32 + r) * B_PITCH + 4 * h : (4 * h) * B_PITCH + wn * 32 + r);
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int64_t kt = kt0 + u;
-            if (kt < nkt) {
-                const int cur = int(kt & 1);
-                // PD == 1: tile kt+1 is requested here and written to LDS in the middle of this iteration.
-                // PD  > 1: slot u (tile kt, in LDS since the last iteration) is refilled with tile kt + PD below, after
-                //          the LDS write of tile kt+1 - whose loads were requested PD-1 iterations ago.
-                if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
-                compute_tile(cur, 0, BK / 2);
-                if (kt + 1 < nkt) {
-                    int64_t younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
-                    if (younger > PD - 2) younger = PD - 2;
-                    wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
-                    store_tile(cur ^ 1, (u + 1) % PD);                // ds_writes issue in the shadow of the second half's MFMAs
+            for (int q = 0; q < HG; ++q) {
+                const int kb = half * (BK / 2) + q * 8;
+                if constexpr (AKC) {
+                    const float4 v = *reinterpret_cast<const float4*>(a + kb);
+                    fa[slot][q][0] = v.x; fa[slot][q][1] = v.y; fa[slot][q][2] = v.z; fa[slot][q][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[slot][q][e] = a[(kb + e) * A_PITCH];
                 }
-                if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
-                compute_tile(cur, BK / 2, BK);
-                __syncthreads();
+                if constexpr (BKC) {
+                    const float4 v = *reinterpret_cast<const float4*>(b + kb);
+                    fb[slot][q][0] = v.x; fb[slot][q][1] = v.y; fb[slot][q][2] = v.z; fb[slot][q][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[slot][q][e] = b[(kb + e) * B_PITCH];
+                }
+            }
+        };
+        auto mfma_half = [&](int slot) {
+#pragma unroll
+            for (int q = 0; q < HG; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][q][e], fb[slot][q][e], acc[0][0], 0, 0, 0);
+        };
+        read_half(0, 0, 0);
+        for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int64_t kt = kt0 + u;
+                if (kt < nkt) {
+                    const int cur = int(kt & 1);
+                    if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
+                    read_half(cur, 1, 1);
+                    mfma_half(0);
+                    if (kt + 1 < nkt) {
+                        int64_t younger = nkt - (kt + 2);
+                        if (younger > PD - 2) younger = PD - 2;
+                        wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
+                        store_tile(cur ^ 1, (u + 1) % PD);
+                    }
+                    if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
+                    __syncthreads();
+                    if (kt + 1 < nkt) read_half(cur ^ 1, 0, 0);
+                    mfma_half(1);
+                }
+            }
+        }
+    } else {
+        for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+    #pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int64_t kt = kt0 + u;
+                if (kt < nkt) {
+                    const int cur = int(kt & 1);
+                    // PD == 1: tile kt+1 is requested here and written to LDS in the middle of this iteration.
+                    // PD  > 1: slot u (tile kt, in LDS since the last iteration) is refilled with tile kt + PD below, after
+                    //          the LDS write of tile kt+1 - whose loads were requested PD-1 iterations ago.
+                    if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
+                    compute_tile(cur, 0, BK / 2);
+                    if (kt + 1 < nkt) {
+                        int64_t younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
+                        if (younger > PD - 2) younger = PD - 2;
+                        wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
+                        store_tile(cur ^ 1, (u + 1) % PD);                // ds_writes issue in the shadow of the second half's MFMAs
+                    }
+                    if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
+                    compute_tile(cur, BK / 2, BK);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -400,9 +461,9 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     hipStream_t s = rt().stream;
     constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 1;
     if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD>), grid, block, 0, s, g);
-    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, PD>), grid, block, 0, s, g);
-    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, PD>), grid, block, 0, s, g);
-    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, PD>), grid, block, 0, s, g);
+    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1>), grid, block, 0, s, g);
+    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1>), grid, block, 0, s, g);
+    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, 1>), grid, block, 0, s, g);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>

@@ -472,14 +472,22 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     g.tiles_m = int((g.M + BM - 1) / BM);
     g.tiles_n = int((g.N + BN - 1) / BN);
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n * batch;
-    // split-K when the tile grid alone cannot fill 256 CUs: aim at >= 512 workgroups, keep >= 2 K-tiles per slice
+    // split-K when the tile grid alone cannot fill the chip.  The slice count minimises a small model of the launch,
+    // fitted to measurements on the MLP / BERT shapes (tools/mlp_gemm_bench.py with LG_GEMM_SLICES):
+    //   K-tiles per workgroup x time per K-tile (x workgroups per CU once they exceed the CUs)  +  cost of the fold
+    // with 0.65 us per K-tile of a lone 64x64 workgroup (0.45 for the two-wave tiles, 2.4 for 128x128) and
+    // 2 + 0.6*slices us for writing, publishing and folding the slabs.
     int64_t slices = 1;
     if (kCanSplitK<BM, BN> && tiles < 256 && g.K >= 4 * BK) {
-        slices = (512 + tiles - 1) / tiles;
-        const int64_t max_slices = g.K / (2 * BK);
-        if (slices > max_slices) slices = max_slices;
-        if (slices > 64) slices = 64;
-        if (slices < 1) slices = 1;
+        const double cus = rt().compute_units > 0 ? rt().compute_units : 256;
+        const double t_iter = BM * BN >= 128 * 128 ? 2.4 : (BM * BN >= 64 * 64 ? 0.65 : 0.45);
+        const int64_t k_tiles = (g.K + BK - 1) / BK;
+        double best = 1e30;
+        for (int64_t sl = 1; sl <= 64 && sl * 2 <= k_tiles; ++sl) {
+            const double per_cu = double(tiles * sl) / cus;
+            const double cost = double((k_tiles + sl - 1) / sl) * t_iter * (per_cu > 1.0 ? per_cu : 1.0) + (sl > 1 ? 2.0 + 0.6 * double(sl) : 0.0);
+            if (cost < best) { best = cost; slices = sl; }
+        }
     }
     static const char* slices_env = getenv("LG_GEMM_SLICES");      // experiments only
     if (kCanSplitK<BM, BN> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);

@@ -176,6 +176,7 @@ class HipTensor(AbstractTensor):
                 from .graph import HipGraph
                 if not HipGraph.capturing:      # while capturing, a fill would only be recorded, not executed
                     seed = HipTensor._unit_seeds[self._shape] = HipTensor.ones(self._shape, requires_grad=False)
+                    seed._is_unit_constant = True       # lets a loss skip the multiplication by its own seed
             if seed is not None:
                 return seed, True
         return HipTensor.ones(self._shape, dtype=self._dtype, requires_grad=False), False

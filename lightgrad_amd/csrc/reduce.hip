@@ -126,11 +126,15 @@ __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ 
 }
 
 // ---- cols / general: one thread per output element --------------------------------------------
+// gridDim.y > 1: the reduced range is split over blockIdx.y.  Each split publishes its partial (write-through store,
+// drained), takes a ticket for its block of 256 outputs, and the workgroup that arrives last folds the partials in
+// split order - the in-launch form of a second pass (cdna_hip_programming.md, in-launch split-K recipe).
 template <int OP>
-__global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, float* __restrict__ partial, RedDesc d,
-                                                int64_t chunk) {
-    const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (o >= d.n_out) return;
+__global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, float* out, float* partial, int* tickets,
+                                                RedDesc d, int64_t chunk) {
+    const int64_t o_raw = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const bool live = o_raw < d.n_out;
+    const int64_t o = live ? o_raw : d.n_out - 1;            // idle lanes of the last block recompute a valid output
     const int64_t split = blockIdx.y;
     const int64_t begin = split * chunk;
     int64_t end = begin + chunk;
@@ -168,9 +172,38 @@ __global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, fl
             }
         }
     }
-    const float v = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
-    float* dst = partial + split * d.n_out + o;
-    *dst = d.accumulate ? *dst + v : v;
+    float v = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+    const int splits = gridDim.y;
+    if (splits > 1) {
+        __hip_atomic_store(partial + split * d.n_out + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int arrived_last;
+        if (threadIdx.x == 0) {
+            int* ticket = tickets + blockIdx.x;
+            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = order == splits - 1;
+            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived_last = last;
+        }
+        __syncthreads();
+        if (!arrived_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        a0 = a1 = a2 = a3 = Red<OP>::identity();
+        const float* q = partial + o;
+        int r = 0;
+        for (; r + 3 < splits; r += 4) {
+            const float x0 = __hip_atomic_load(q + int64_t(r) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float x1 = __hip_atomic_load(q + int64_t(r + 1) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float x2 = __hip_atomic_load(q + int64_t(r + 2) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float x3 = __hip_atomic_load(q + int64_t(r + 3) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a0 = Red<OP>::comb(a0, x0); a1 = Red<OP>::comb(a1, x1); a2 = Red<OP>::comb(a2, x2); a3 = Red<OP>::comb(a3, x3);
+        }
+        for (; r < splits; ++r)
+            a0 = Red<OP>::comb(a0, __hip_atomic_load(q + int64_t(r) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        v = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+    }
+    if (live) out[o] = d.accumulate ? out[o] + v : v;
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -248,21 +281,16 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
     int64_t chunk = (d.rlen + splits - 1) / splits;
     splits = (d.rlen + chunk - 1) / chunk;
     if (blocks_x >= (int64_t(1) << 31)) { set_error("lg_reduce: output too large"); return LG_EINVAL; }
+    if (splits > 1 && blocks_x > rt().n_gemm_tickets) { splits = 1; chunk = d.rlen; }     // more output blocks than tickets
     if (splits == 1) {
-        hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, in, out, d, chunk);
+        hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, in, out, nullptr, nullptr, d, chunk);
         return LG_OK;
     }
     float* partial = nullptr;
     int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
     if (rc != LG_OK) return rc;
-    RedDesc d1 = d;
-    d1.accumulate = 0;
-    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, s, in, partial, d1, chunk);
-    RedDesc d2{};
-    d2.accumulate = d.accumulate;
-    d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
-    d2.kshape[0] = d.n_out; d2.kstride[0] = 1; d2.rshape[0] = splits; d2.rstride[0] = d.n_out;
-    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), 1), dim3(256), 0, s, partial, out, d2, splits);
+    hipLaunchKernelGGL((red_cols<OP>), dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, s, in, out, partial,
+                       rt().gemm_tickets, d, chunk);
     return lg_free(partial);
 }
 

@@ -24,6 +24,8 @@ class mse(Function):
 
     def backward(ctx, out_grad):
         err, = ctx.get_saved_tensors()
+        if getattr(out_grad, "_is_unit_constant", False):
+            return err          # the loss is the root of backward(): its seed is the backend's constant 1.0, and x * 1.0 is x
         return err * out_grad
 
 
@@ -44,7 +46,7 @@ class cross_entropy(Function):
     def backward(ctx, out_grad):
         p, y_hat, axis = ctx.get_saved_tensors()
         if y_hat is None:
-            return p * out_grad
+            return p if getattr(out_grad, "_is_unit_constant", False) else p * out_grad
         n = y_hat.shape[0]
         p[range(n), y_hat] -= 1
         p /= n

@@ -285,7 +285,7 @@ def _collapse_batch(shape, strides):
     return n, st
 
 
-def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None):
+def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=False):
     """a (..., M, K) @ b (..., K, N) [+ bias (N,)] -> (..., M, N) on the MFMA SGEMM kernel.
 
     Operands are consumed in place whenever one of their last two dims has stride 1
@@ -355,7 +355,8 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None):
                                    pb, mb.ld, strb, pa, ma.ld, stra, po, M, stro, count, 0))
         else:
             _l.check(L.lg_gemm_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
-                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, 1 if accumulate_into is not None else 0))
+                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count,
+                                   1 if (accumulate_into is not None and not overwrite) else 0))
 
     if nb > 0 and M > 0 and N > 0:
         ca, cb = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb)
@@ -423,10 +424,10 @@ class dot(Function):
             # dense 2-D leaves that already own a gradient buffer: accumulate in the GEMM epilogue (see linear.backward)
             acc_a, acc_b = a._grad_accumulator(), b._grad_accumulator()
             if a.requires_grad and acc_a is not None and acc_a.is_contiguous() and a is not b:
-                _gemm(out_grad, _swap_last(b), accumulate_into=acc_a)
+                _gemm(out_grad, _swap_last(b), accumulate_into=acc_a, overwrite=a._consume_zero_pending())
                 ga = False
             if b.requires_grad and acc_b is not None and acc_b.is_contiguous() and a is not b:
-                _gemm(_swap_last(a), out_grad, accumulate_into=acc_b)
+                _gemm(_swap_last(a), out_grad, accumulate_into=acc_b, overwrite=b._consume_zero_pending())
                 gb = False
         if ga is None:
             ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
@@ -600,15 +601,17 @@ def _norm_axes(nd, axis):
     return axes
 
 
-def _reduce_into(acc, x, axes):
-    """acc += x.sum(axes): the reduction's final pass adds into an existing dense buffer (lg_reduce_acc)"""
+def _reduce_into(acc, x, axes, overwrite=False):
+    """acc += x.sum(axes) (or acc = ... after a lazy zero_grad): the reduction's final pass adds into an existing dense
+    buffer (lg_reduce_acc)"""
     _require_f32(x, acc)
     mask = 0
     for a in axes:
         mask |= 1 << a
     kept = tuple(s for i, s in enumerate(x._shape) if i not in axes)
     assert acc._shape == kept and acc.is_contiguous()
-    _l.check(_l.lib().lg_reduce_acc(_l.RED_SUM, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, acc.ptr, 1))
+    _l.check(_l.lib().lg_reduce_acc(_l.RED_SUM, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, acc.ptr,
+                                    0 if overwrite else 1))
 
 
 def _reduce(op, x, axes, keepdims):
@@ -763,13 +766,13 @@ class linear(Function):
         if weight.requires_grad:
             acc = weight._grad_accumulator()
             if acc is not None and acc.is_contiguous():
-                _gemm(_swap_last(g2), x2, accumulate_into=acc)
+                _gemm(_swap_last(g2), x2, accumulate_into=acc, overwrite=weight._consume_zero_pending())
             else:
                 dw = _gemm(_swap_last(g2), x2)
         if x.requires_grad:
             acc = x._grad_accumulator()
             if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
-                _gemm(g2, weight, accumulate_into=acc)
+                _gemm(g2, weight, accumulate_into=acc, overwrite=x._consume_zero_pending())
             else:
                 dx = _gemm(g2, weight).reshape(*x._shape)
         if not has_bias:
@@ -777,7 +780,7 @@ class linear(Function):
         if bias.requires_grad:
             acc = bias._grad_accumulator()
             if acc is not None and acc.is_contiguous():
-                _reduce_into(acc, g2, (0,))
+                _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())
             else:
                 db = _reduce(_l.RED_SUM, g2, (0,), False)
         return dx, dw, db

@@ -38,6 +38,12 @@ class AbstractTensor(metaclass=_TensorType):
     # Values are identical to the copying form; it only removes one device copy per tape node.
     _adopt_first_grad = False
 
+    # Set by an optimizer's zero_grad in place of the fill: "this gradient buffer counts as zeros".  The first kernel
+    # that would accumulate into it overwrites it instead (`_consume_zero_pending`); anything else that looks at the
+    # gradient first gets the zeros written for real (`grad`, `add_grad`, `_materialize_zero_grad`).  Same values as
+    # fill(0) followed by +=, one pass over the buffer less.
+    _grad_zero_pending = False
+
     def __init__(self, data, requires_grad: bool = True) -> None:
         self._data = data
         self._grad = None
@@ -69,7 +75,19 @@ class AbstractTensor(metaclass=_TensorType):
 
     @property
     def grad(self) -> "AbstractTensor":
+        if self._grad_zero_pending:
+            self._materialize_zero_grad()
         return self._grad
+
+    def _materialize_zero_grad(self) -> None:
+        if self._grad_zero_pending:
+            self._grad_zero_pending = False
+            self._grad.fill(0)
+
+    def _consume_zero_pending(self) -> bool:
+        """True once after a lazy zero_grad: the caller then WRITES its gradient into `_grad_accumulator()`"""
+        pending, self._grad_zero_pending = self._grad_zero_pending, False
+        return pending
 
     @property
     def requires_grad(self) -> bool:
@@ -156,6 +174,7 @@ class AbstractTensor(metaclass=_TensorType):
             elif self._grad_shared:
                 self._grad, self._grad_shared = self._grad + grad, False
             else:
+                self._materialize_zero_grad()
                 self._grad += grad
         finally:
             Gradients.enable()
@@ -186,6 +205,7 @@ class AbstractTensor(metaclass=_TensorType):
                         stack.append(p)
 
     def _zero_own_grad(self) -> None:
+        self._grad_zero_pending = False
         if self._requires_grad:
             if self._grad is None or self._grad_shared:
                 self._grad, self._grad_shared = self.__class__.zeros(self.shape, requires_grad=False), False

@@ -262,6 +262,8 @@ class DataParallel(object):
     def sync_gradients(self):
         """sum the gradient bucket over all ranks, in place, asynchronously"""
         if self.comm.world_size > 1 or getattr(self, "always_sync", False):
+            for p in self.parameters:
+                p._materialize_zero_grad()        # a lazily zeroed gradient no kernel has written yet (optim.zero_grad)
             self.comm.allreduce_sum_(self.bucket)
 
     def parameter_digest(self) -> float:

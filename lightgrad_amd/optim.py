@@ -29,7 +29,9 @@ class Optimizer(object):
 
     def zero_grad(self) -> None:
         if self._flat_grad is not None:
-            self._flat_grad.fill(0)           # every p.grad is a view into this bucket
+            # every p.grad is a view into the bucket, written by the first backward kernel that reaches it
+            for p in self.parameters:
+                p._grad_zero_pending = True
             return
         for p in self.parameters:
             p.zero_grad()
@@ -98,6 +100,8 @@ class Adam(Optimizer):
     def step(self) -> None:
         n_params = len(self.parameters)
         if self._flat is not None:
+            for p in self.parameters:
+                p._materialize_zero_grad()        # parameters no gradient reached since zero_grad
             flat_p, flat_m, flat_v, offsets = self._flat
             flat_p._fused_adam_multi_dev(self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2, self.eps,
                                          self._step_counter, self.grad_scale, self.belief)   # advances the device counter too

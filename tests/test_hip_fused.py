@@ -111,3 +111,47 @@ def test_fused_cross_entropy_full_size_and_views(hip):
     np.testing.assert_allclose(yt.grad.numpy(), want_grad.T, rtol=1e-5, atol=1e-8)
     with pytest.raises(AssertionError):
         light.loss.cross_entropy(y, hip.from_numpy(labels.astype(np.float32), requires_grad=False))
+
+
+def test_lazy_zero_grad_equals_fill_then_accumulate(hip):
+    """flat-bucket zero_grad only MARKS the gradients as zero: the first backward kernel overwrites, later ones add
+    (a layer used twice), a parameter no gradient reaches reads as zeros and stays put.  Same trajectory as the
+    per-parameter optimizer with its eager fill."""
+    from lightgrad_amd.dist import DataParallel, SingleProcess
+
+    class Net(light.nn.Module):
+        def __init__(self):
+            light.nn.Module.__init__(self)
+            self.shared = light.nn.Linear(12, 12)
+            self.head = light.nn.Linear(12, 5)
+            self.unused = light.nn.Linear(3, 3)
+
+        def forward(self, x):
+            return self.head(self.shared(self.shared(x).relu()).relu())
+
+    rng = np.random.RandomState(2)
+    x_np, t_np = rng.uniform(-1, 1, (16, 12)).astype(np.float32), rng.uniform(0, 1, (16, 5)).astype(np.float32)
+    results = []
+    for flat in (False, True):
+        np.random.seed(11)
+        model = Net().map_parameters(lambda p: p.hip())
+        x, t = hip.from_numpy(x_np, requires_grad=False), hip.from_numpy(t_np, requires_grad=False)
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-2, fused=True, device_step=flat)
+        if flat:
+            DataParallel(model.parameters(), SingleProcess(), flatten=True).attach(opt)
+        for step in range(4):
+            loss = light.loss.mse(model(x), t)
+            opt.zero_grad()
+            if flat:
+                assert all(p._grad_zero_pending for p in model.parameters())
+            loss.backward()
+            if flat:
+                assert not model.shared.weight._grad_zero_pending and model.unused.weight._grad_zero_pending
+                if step == 0:
+                    assert not model.unused.weight.grad.numpy().any()          # reading it writes the zeros
+            opt.step()
+            assert not any(p._grad_zero_pending for p in model.parameters())
+        results.append({n: p.numpy() for n, p in model.named_parameters()})
+        results[-1]["grad"] = model.shared.weight.grad.numpy()
+    for name in results[0]:
+        np.testing.assert_allclose(results[1][name], results[0][name], rtol=1e-5, atol=1e-7, err_msg=name)

@@ -198,6 +198,15 @@ int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, const float* bias);
 
+/* C (+)= op(A) @ op(B) and, from the same launch, rowsum (+)= row sums of op(A) (one matrix product, no batch).
+ * With op(A) = g^T this is the weight gradient dW = g^T @ x together with the bias gradient db = column sums of g -
+ * the dot.backward GEMM (cpu/ops.py:116) plus the un-broadcasting `sum(axis=0, keepdims=True)` of func.py:50-56 for
+ * nn.Linear's `+ b` (nn.py:96).  The sums are column N of the product against a virtual column of ones appended to
+ * op(B), i.e. they come off the same MFMA accumulators. */
+int lg_gemm_rowsum_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                       const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, int accumulate, float* rowsum, int rowsum_accumulate);
+
 /* ---- fused optimizer ---------------------------------
  * One Adam/AdaBelief update of a contiguous parameter, numerically the
  * expression sequence of optim.py:36-40 / :48-52 evaluated per element (one

@@ -382,6 +382,24 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
     return out
 
 
+def _gemm_rowsum(a, b, accumulate_into=None, overwrite=False, rowsum_into=None, rowsum_overwrite=False):
+    """(a @ b, a.sum(axis=1)) for 2-D operands from ONE launch (lg_gemm_rowsum_f32): the row sums are the product with a
+    virtual column of ones.  With a = g^T, b = x this is nn.Linear's (dW, db).  Either result may be added into / written
+    over an existing dense buffer (a parameter's gradient)."""
+    _require_f32(a, b)
+    (M, K), (K2, N) = a._shape, b._shape
+    assert K == K2 and M > 0 and N > 0
+    ma, mb = _as_mat(a), _as_mat(b)
+    for t, shape in ((accumulate_into, (M, N)), (rowsum_into, (M,))):
+        assert t is None or (t._shape == shape and t.is_contiguous() and t._dtype == _F32)
+    out = accumulate_into if accumulate_into is not None else HipTensor.empty((M, N))
+    rowsum = rowsum_into if rowsum_into is not None else HipTensor.empty((M,))
+    _l.check(_l.lib().lg_gemm_rowsum_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K, ma.t.ptr, ma.ld, mb.t.ptr, mb.ld,
+                                         out.ptr, N, 1 if (accumulate_into is not None and not overwrite) else 0,
+                                         rowsum.ptr, 1 if (rowsum_into is not None and not rowsum_overwrite) else 0))
+    return out, rowsum
+
+
 def _is_colmajor(t):
     return len(t._shape) >= 2 and t._strides[-2] == 1 and t._shape[-1] > 1 and t._strides[-1] != 1
 
@@ -763,7 +781,19 @@ class linear(Function):
         # gradient ADDED in place by the producing kernel (GEMM with beta = 1 / reduction with accumulate) and None
         # is reported for them - tensor.py:118's `grad += g` without the temporary and the extra pass
         dw = dx = db = None
-        if weight.requires_grad:
+        want_db = has_bias and bias.requires_grad
+        if weight.requires_grad and want_db and g2._shape[0] > 0:
+            # dW and db from one launch: db = column sums of g = row sums of g^T, a virtual extra column of the product
+            acc_w, acc_b = weight._grad_accumulator(), bias._grad_accumulator()
+            acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+            acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+            out_w, out_b = _gemm_rowsum(_swap_last(g2), x2, accumulate_into=acc_w,
+                                        overwrite=acc_w is not None and weight._consume_zero_pending(),
+                                        rowsum_into=acc_b, rowsum_overwrite=acc_b is not None and bias._consume_zero_pending())
+            dw = out_w if acc_w is None else None
+            db = out_b if acc_b is None else None
+            want_db = False
+        elif weight.requires_grad:
             acc = weight._grad_accumulator()
             if acc is not None and acc.is_contiguous():
                 _gemm(_swap_last(g2), x2, accumulate_into=acc, overwrite=weight._consume_zero_pending())
@@ -777,7 +807,7 @@ class linear(Function):
                 dx = _gemm(g2, weight).reshape(*x._shape)
         if not has_bias:
             return dx, dw
-        if bias.requires_grad:
+        if want_db:
             acc = bias._grad_accumulator()
             if acc is not None and acc.is_contiguous():
                 _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())

@@ -54,6 +54,10 @@ struct GemmArgs {
     int64_t k_per_slice;    // multiple of BK
     float*  W;
     int*    tickets;        // one per (batch, tile), zero on entry and on exit
+    // optional row sums of op(A) (= the bias gradient when op(A) = g^T, nn.py:96 / func.py:50-56): computed as column N
+    // of C against a VIRTUAL column of ones appended to op(B) - the tiling, split-K and fold treat it like any column
+    float*  rowsum;         // [M] or NULL
+    int     rowsum_accumulate;
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -113,6 +117,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const float* __restrict__ bias = g.bias;
     const int64_t k_begin = int64_t(slice) * g.k_per_slice;
     const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
+    // the virtual ones-column (row sums of A) lives in column N of this workgroup's tile, if at all
+    const bool has_virtual = kCanSplitK<BM, BN> && g.rowsum != nullptr && n0 <= g.N && g.N < n0 + BN;
 
     // staging registers: a ring of PD K-tiles in flight between global memory and LDS (PD = 1: the tile fetched at the
     // top of an iteration is written to LDS in its middle; small tiles have too few MFMAs per K-tile to cover the
@@ -131,6 +137,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     // no zero-fill moves in the K loop.
     constexpr unsigned OOB = 0x80000000u;            // == num_records
     unsigned offA[A_CHUNKS], offB[B_CHUNKS];
+    unsigned virt_mask = 0;                          // B chunks of this thread that start at the virtual column
+    int krem_ring[PD];                               // k extent of the tile waiting in each ring slot
     int kcA[A_CHUNKS], kcB[B_CHUNKS];                // k coordinate of the chunk inside its K-tile
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
@@ -151,6 +159,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         kcB[i] = kk;
         const int64_t bytes = BKC ? (int64_t(col) * g.ldb + kk) * 4 : (int64_t(kk) * g.ldb + col) * 4;
         offB[i] = (n0 + col < g.N) ? unsigned(bytes) : OOB;
+        if (has_virtual && n0 + col == g.N) virt_mask |= 1u << i;
     }
     const float* const Atile0 = AKC ? A + m0 * g.lda : A + m0;      // + k0 (AKC) / + k0 * lda per K-tile
     const float* const Btile0 = BKC ? B + n0 * g.ldb : B + n0;
@@ -166,6 +175,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     };
     auto load_tile = [&](int64_t k0, int slot) {
         const int krem = int(k_end - k0 < BK ? k_end - k0 : BK);     // k values of this tile inside the slice
+        krem_ring[slot] = krem;
         const u32x4 da = descriptor(AKC ? Atile0 + k0 : Atile0 + k0 * g.lda);
         const u32x4 db = descriptor(BKC ? Btile0 + k0 : Btile0 + k0 * g.ldb);
 #pragma unroll
@@ -204,6 +214,20 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             } else {
                 if constexpr (AKC) a[(f / BK) * A_PITCH + (f % BK)] = ra_ring[slot][i];
                 else               a[(f / BM) * A_PITCH + (f % BM)] = ra_ring[slot][i];
+            }
+        }
+        if constexpr (kCanSplitK<BM, BN>) if (has_virtual) {
+            // the loads returned zeros for the virtual column (beyond N): put the ones in, for the k values that exist
+#pragma unroll
+            for (int i = 0; i < B_CHUNKS; ++i) {
+                const bool virt = (virt_mask >> i) & 1u, kv = kcB[i] < krem_ring[slot];
+                const float one = kv ? 1.0f : 0.0f;
+                if constexpr (VB) {
+                    if constexpr (BKC) { if (virt) rb_ring[slot][i] = f32x4{one, one, one, one}; }      // row N of B^T: ones along k
+                    else               { if (virt) rb_ring[slot][i] = f32x4{one, 0.f, 0.f, 0.f}; }     // k-row of B: column N, then beyond
+                } else {
+                    if (virt) rb_ring[slot][i] = one;
+                }
             }
         }
 #pragma unroll
@@ -432,14 +456,18 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         for (int j = 0; j < TN; ++j) {
             const int64_t col = n0 + (wn * TN + j) * 32 + r;
             const int64_t row0 = m0 + (wm * TM + i) * 32 + 4 * h;
-            if (col < g.N) {
-                const float bv = bias ? bias[col] : 0.f;
+            const bool vcol = has_virtual && col == g.N;             // this lane holds row sums, not a column of C
+            if (col < g.N || vcol) {
+                const float bv = (bias && !vcol) ? bias[col] : 0.f;
+                float* const dst = vcol ? g.rowsum : C + col;
+                const int64_t dstride = vcol ? 1 : ldc;
+                const bool acc_flag = vcol ? g.rowsum_accumulate != 0 : accumulate != 0;
                 float old[16];
-                if (accumulate) {      // C += ...: fetch the 16 old values first so the loads overlap, then add and store
+                if (acc_flag) {        // C += ...: fetch the 16 old values first so the loads overlap, then add and store
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                        old[e] = row < g.M ? C[row * ldc + col] : 0.f;
+                        old[e] = row < g.M ? dst[row * dstride] : 0.f;
                     }
                 }
 #pragma unroll
@@ -447,7 +475,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                     const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
                     if (row < g.M) {
                         const float val = bias ? acc[i][j][e] + bv : acc[i][j][e];
-                        C[row * ldc + col] = accumulate ? old[e] + val : val;
+                        dst[row * dstride] = acc_flag ? old[e] + val : val;
                     }
                 }
             }
@@ -470,7 +498,7 @@ template <int BM, int BN, int BK, int WM, int WN>
 static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
     GemmArgs g = base;
     g.tiles_m = int((g.M + BM - 1) / BM);
-    g.tiles_n = int((g.N + BN - 1) / BN);
+    g.tiles_n = int((g.N + (g.rowsum ? 1 : 0) + BN - 1) / BN);
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n * batch;
     // split-K when the tile grid alone cannot fill the chip.  The slice count minimises a small model of the launch,
     // fitted to measurements on the MLP / BERT shapes (tools/mlp_gemm_bench.py with LG_GEMM_SLICES):
@@ -523,7 +551,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      const float* A, int64_t lda, int64_t strideA,
                      const float* B, int64_t ldb, int64_t strideB,
                      float* C, int64_t ldc, int64_t strideC,
-                     int64_t batch, int accumulate, const float* bias) {
+                     int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -532,8 +560,14 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     LG_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N,
            "lg_gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld for M=%lld N=%lld K=%lld tA=%d tB=%d)",
            (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, transA, transB);
+    LG_ARG(rowsum == nullptr || (batch == 1 && bias == nullptr), "lg_gemm_rowsum_f32: one matrix product, no bias");
     if (K == 0) {
         LG_ARG(bias == nullptr, "lg_gemm_bias_f32: K == 0 with a bias is not supported");
+        if (rowsum && !rowsum_accumulate) {
+            int64_t shape1[1] = {M}, st1[1] = {1};
+            int rc1 = lg_fill_strided(4, 1, shape1, rowsum, st1, 0);
+            if (rc1 != LG_OK) return rc1;
+        }
         if (accumulate) return LG_OK;
         // empty sum: C = 0
         int64_t shape[3] = {batch, M, N}, st[3] = {strideC, ldc, 1};
@@ -550,6 +584,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.accumulate = accumulate;
     g.bias = bias;
+    g.rowsum = rowsum;
+    g.rowsum_accumulate = rowsum_accumulate;
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
     if (g.group_m < 1) g.group_m = 1;
@@ -585,12 +621,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const int64_t per_cu = (nblocks(bm, bn) + cus - 1) / cus;
                 return double(per_cu) * double(bm * bn) / eff;
             };
-            const double c256 = cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
+            const double c256 = rowsum ? 1e300 : cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
             tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
         }
         switch (tile) {
             case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
-            case 2:  rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break;
+            case 2:  if (!rowsum) { rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break; }   // else: 128
             case 9:  rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
             default: rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
         }
@@ -614,4 +650,11 @@ extern "C" int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, in
                                 float* C, int64_t ldc, int64_t strideC,
                                 int64_t batch, const float* bias) {
     return gemm_impl(transA, transB, M, N, K, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, batch, 0, bias);
+}
+
+extern "C" int lg_gemm_rowsum_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                                  float* C, int64_t ldc, int accumulate, float* rowsum, int rowsum_accumulate) {
+    LG_ARG(rowsum != nullptr, "lg_gemm_rowsum_f32: rowsum is NULL");
+    return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, accumulate, nullptr, rowsum, rowsum_accumulate);
 }

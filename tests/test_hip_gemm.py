@@ -153,3 +153,34 @@ def test_4096_forward_backward_properties(hip):
     # (4) linearity: (2A) @ B == 2 (A @ B) exactly (power-of-two scaling commutes with rounding)
     y2 = ((ta * 2.0) @ tb).numpy()
     np.testing.assert_array_equal(y2, 2 * yn)
+
+
+@pytest.mark.parametrize("mkn", [(512, 1024, 784), (10, 1024, 512), (64, 64, 64), (64, 100, 128), (33, 31, 35), (130, 700, 63),
+                                 (1, 5, 1), (200, 36, 300), (128, 2048, 128), (7, 3, 2), (256, 512, 255)])
+def test_rowsum_column_of_the_product(hip, mkn):
+    """lg_gemm_rowsum_f32: C = A @ B and the row sums of A from one launch (virtual ones-column), every layout,
+    N on and off the tile boundary, split-K sizes, write and accumulate modes; plus the nn.Linear (dW, db) use"""
+    from lightgrad_amd.autograd.hip import ops as H
+    M, K, N = mkn
+    rng = np.random.RandomState(M + 13 * K + 101 * N)
+    a, b = rng.uniform(-1, 1, (M, K)).astype(np.float32), rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    ref, ref_rs = a.astype(np.float64) @ b.astype(np.float64), a.astype(np.float64).sum(1)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    ta_t = hip.from_numpy(np.ascontiguousarray(a.T)).transpose(1, 0)
+    tb_t = hip.from_numpy(np.ascontiguousarray(b.T)).transpose(1, 0)
+    atol_rs = 1e-6 * K ** 0.5 * 4
+    for x, y, tag in [(ta, tb, "NN"), (ta, tb_t, "NT"), (ta_t, tb, "TN"), (ta_t, tb_t, "TT")]:
+        out, rs = H._gemm_rowsum(x, y)
+        assert rel_err(out.numpy(), ref) <= 1e-5, tag
+        np.testing.assert_allclose(rs.numpy(), ref_rs, rtol=1e-5, atol=atol_rs, err_msg=tag)
+    c0, r0 = rng.uniform(-1, 1, (M, N)).astype(np.float32), rng.uniform(-1, 1, (M,)).astype(np.float32)
+    tc, tr = hip.from_numpy(c0), hip.from_numpy(r0)
+    H._gemm_rowsum(ta_t, tb, accumulate_into=tc, rowsum_into=tr)                       # both accumulate
+    assert rel_err(tc.numpy(), ref + c0) <= 1e-5
+    np.testing.assert_allclose(tr.numpy(), ref_rs + r0, rtol=1e-5, atol=atol_rs)
+    H._gemm_rowsum(ta_t, tb, accumulate_into=tc, overwrite=True, rowsum_into=tr)       # C overwritten, sums accumulate again
+    assert rel_err(tc.numpy(), ref) <= 1e-5
+    np.testing.assert_allclose(tr.numpy(), 2 * ref_rs + r0, rtol=1e-5, atol=2 * atol_rs)
+    H._gemm_rowsum(ta_t, tb, accumulate_into=tc, rowsum_into=tr, rowsum_overwrite=True)
+    assert rel_err(tc.numpy(), 2 * ref) <= 1e-5
+    np.testing.assert_allclose(tr.numpy(), ref_rs, rtol=1e-5, atol=atol_rs)

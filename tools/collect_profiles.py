@@ -6,12 +6,16 @@ src, dst = "gpurun_out/final", os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_%s.json" % tag))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "bench_under_rocprof_%s.json" % tag))
-shutil.copy(glob.glob(src + "/stats/*/*_kernel_stats.csv")[0], os.path.join(dst, "bench_kernel_stats_%s.csv" % tag))
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # gpurun merges into gpurun_out/: older runs may linger
+shutil.copy(newest(src + "/stats/*/*_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats_%s.csv" % tag))
 shutil.copy(os.path.join(src, "mlp_step_trace.txt"), os.path.join(dst, "mlp_step_trace_%s.txt" % tag))
 shutil.copy(os.path.join(src, "gemm_sweep.txt"), os.path.join(dst, "gemm_sweep_%s.txt" % tag))
+for extra in ("hbm_bench", "mlp_gemm_bench"):
+    if os.path.exists(os.path.join(src, extra + ".txt")):
+        shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
 pmc = {}
 for kind in ("fetch", "write"):
-    f = glob.glob("%s/%s/*/*_counter_collection.csv" % (src, kind))[0]
+    f = newest("%s/%s/*/*_counter_collection.csv" % (src, kind))
     shutil.copy(f, os.path.join(dst, "pmc_%s_size_%s.csv" % (kind, tag)))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):

@@ -9,3 +9,5 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 tools/profile_kernels.py > $out/write.log 2>&1; echo "write rc=$?"
 python tools/step_trace.py $out/stats/*/*_kernel_trace.csv > $out/mlp_step_trace.txt; tail -1 $out/mlp_step_trace.txt
 for n in 1024 2048 3072 4096 8192; do timeout -k 5 100 python tools/gemm_bench.py $n 3; done > $out/gemm_sweep.txt 2>&1; cat $out/gemm_sweep.txt
+timeout -k 10 200 python tools/hbm_bench.py > $out/hbm_bench.txt 2>&1; tail -3 $out/hbm_bench.txt
+timeout -k 10 100 python tools/mlp_gemm_bench.py > $out/mlp_gemm_bench.txt 2>&1; cat $out/mlp_gemm_bench.txt

@@ -189,19 +189,23 @@ __global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, fl
         __syncthreads();
         if (!arrived_last) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        a0 = a1 = a2 = a3 = Red<OP>::identity();
+        // 8 partials in flight per thread (their loads cross XCDs: ~1 us each), combined in a fixed order
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = Red<OP>::identity();
         const float* q = partial + o;
         int r = 0;
-        for (; r + 3 < splits; r += 4) {
-            const float x0 = __hip_atomic_load(q + int64_t(r) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float x1 = __hip_atomic_load(q + int64_t(r + 1) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float x2 = __hip_atomic_load(q + int64_t(r + 2) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float x3 = __hip_atomic_load(q + int64_t(r + 3) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a0 = Red<OP>::comb(a0, x0); a1 = Red<OP>::comb(a1, x1); a2 = Red<OP>::comb(a2, x2); a3 = Red<OP>::comb(a3, x3);
+        for (; r + 7 < splits; r += 8) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = __hip_atomic_load(q + int64_t(r + e) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = Red<OP>::comb(f[e], x[e]);
         }
         for (; r < splits; ++r)
-            a0 = Red<OP>::comb(a0, __hip_atomic_load(q + int64_t(r) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        v = Red<OP>::comb(Red<OP>::comb(a0, a1), Red<OP>::comb(a2, a3));
+            f[0] = Red<OP>::comb(f[0], __hip_atomic_load(q + int64_t(r) * d.n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        v = Red<OP>::comb(Red<OP>::comb(Red<OP>::comb(f[0], f[1]), Red<OP>::comb(f[2], f[3])),
+                          Red<OP>::comb(Red<OP>::comb(f[4], f[5]), Red<OP>::comb(f[6], f[7])));
     }
     if (live) out[o] = d.accumulate ? out[o] + v : v;
 }
@@ -275,6 +279,10 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
     if (blocks_x < col_blocks && d.rlen >= 64) {
         splits = col_blocks / blocks_x;
         if (splits * 16 > d.rlen) splits = d.rlen / 16;           // at least 16 elements per thread
+        // the workgroup that folds reads one partial per split and thread, 8 at a time across XCDs: beyond ~32 splits
+        // that serial tail outweighs the extra parallelism (4096^2: 96 splits 34 us, 32 splits 21 us)
+        const int64_t cap = d.rlen >= 8192 ? 64 : 32;
+        if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
         if (splits > 65535) splits = 65535;
     }

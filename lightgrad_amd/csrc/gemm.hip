@@ -574,9 +574,16 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
         return lg_fill_strided(4, 3, shape, C, st, 0);
     }
 
-    // operand tiles are addressed with 32-bit byte offsets from a per-tile descriptor base (at most 256 rows / k-steps)
-    LG_ARG(lda < (int64_t(1) << 20) && ldb < (int64_t(1) << 20), "lg_gemm_f32: leading dimension >= 2^20 elements (lda=%lld ldb=%lld)",
-           (long long)lda, (long long)ldb);
+    // operand tiles are addressed with 32-bit byte offsets from a per-tile descriptor base: the farthest element of a
+    // tile (at most 256 rows of a K-contiguous operand, 32 k-rows of the other kind) must stay below 2 GiB
+    {
+        auto far = [](bool k_contiguous, int64_t rows, int64_t ld) {
+            const int64_t lines = k_contiguous ? (rows < 256 ? rows : 256) : 32;
+            return (lines - 1) * ld * 4 + 1024;
+        };
+        LG_ARG(far(!transA, M, lda) < (int64_t(1) << 31) && far(transB != 0, N, ldb) < (int64_t(1) << 31),
+               "lg_gemm_f32: leading dimension too large for 32-bit tile offsets (lda=%lld ldb=%lld)", (long long)lda, (long long)ldb);
+    }
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
     g.M = M; g.N = N; g.K = K;

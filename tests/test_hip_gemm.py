@@ -184,3 +184,20 @@ def test_rowsum_column_of_the_product(hip, mkn):
     H._gemm_rowsum(ta_t, tb, accumulate_into=tc, rowsum_into=tr, rowsum_overwrite=True)
     assert rel_err(tc.numpy(), 2 * ref) <= 1e-5
     np.testing.assert_allclose(tr.numpy(), ref_rs, rtol=1e-5, atol=atol_rs)
+
+
+def test_long_vectors_and_wide_rows(hip):
+    """inner products of multi-million-element vectors and few-row operands with a very long leading dimension
+    (tile offsets are 32-bit: the limit depends on rows x ld, not on ld alone)"""
+    rng = np.random.RandomState(9)
+    n = 3_000_001
+    a, b = rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    ref = float(a.astype(np.float64) @ b.astype(np.float64))
+    assert abs((ta @ tb).item() - ref) <= 1e-5 * float(np.abs(a.astype(np.float64) * b).sum())
+    m = rng.uniform(-1, 1, (3, n)).astype(np.float32)
+    got = (hip.from_numpy(m) @ tb).numpy()
+    ref3 = m.astype(np.float64) @ b.astype(np.float64)
+    np.testing.assert_allclose(got, ref3, atol=1e-5 * n ** 0.5 * 4)
+    outer = (ta.reshape(n, 1)[:70000] @ tb.reshape(1, n)[:, :5]).numpy()          # K = 1
+    np.testing.assert_array_equal(outer, a[:70000, None] * b[None, :5])

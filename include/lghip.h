@@ -198,6 +198,16 @@ int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, const float* bias);
 
+/* lg_gemm_f32 over a TWO-level batch: matrix (o, i) of operand X starts at X + o*strideX_outer + i*strideX_inner.
+ * One launch for attention-shaped products whose (batch, head) dims do not collapse into one stride after the head
+ * split `reshape(b, s, h, d).transpose(0, 2, 1, 3)` (examples/bert.py:70-95; the reference's kernel is launched per
+ * batch by kernels.dot, opencl/kernels.py:318-334). */
+int lg_gemm_batched2_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                         const float* A, int64_t lda, int64_t strideA_outer, int64_t strideA_inner,
+                         const float* B, int64_t ldb, int64_t strideB_outer, int64_t strideB_inner,
+                         float* C, int64_t ldc, int64_t strideC_outer, int64_t strideC_inner,
+                         int64_t batch_outer, int64_t batch_inner, int accumulate);
+
 /* C (+)= op(A) @ op(B) and, from the same launch, rowsum (+)= row sums of op(A) (one matrix product, no batch).
  * With op(A) = g^T this is the weight gradient dW = g^T @ x together with the bias gradient db = column sums of g -
  * the dot.backward GEMM (cpu/ops.py:116) plus the un-broadcasting `sum(axis=0, keepdims=True)` of func.py:50-56 for

@@ -362,9 +362,21 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
         ca, cb = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb)
         if ca is not None and cb is not None:
             launch(a.ptr, b.ptr, out.ptr, nb, ca[1], cb[1], M * N)
+        elif (bias is None and len(batch_shape) >= 2
+              and _collapse_batch(batch_shape[:-1], sa[:-1]) is not None and _collapse_batch(batch_shape[:-1], sb[:-1]) is not None):
+            # attention after the head split: (batch, head) do not walk as ONE stride, but as two - still one launch
+            (n_outer, a_outer), (_, b_outer) = _collapse_batch(batch_shape[:-1], sa[:-1]), _collapse_batch(batch_shape[:-1], sb[:-1])
+            inner = batch_shape[-1]
+            if out_colmajor:      # C^T = B^T @ A^T, as in launch()
+                _l.check(L.lg_gemm_batched2_f32(0 if mb.colmajor else 1, 0 if ma.colmajor else 1, N, M, K,
+                                                b.ptr, mb.ld, b_outer, sb[-1], a.ptr, ma.ld, a_outer, sa[-1],
+                                                out.ptr, M, inner * M * N, M * N, n_outer, inner, 0))
+            else:
+                _l.check(L.lg_gemm_batched2_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
+                                                a.ptr, ma.ld, a_outer, sa[-1], b.ptr, mb.ld, b_outer, sb[-1],
+                                                out.ptr, N, inner * M * N, M * N, n_outer, inner, 0))
         else:
-            # batch dims that do not collapse (e.g. attention heads split by a transpose): loop over the
-            # leading dims, batch the innermost one
+            # batch dims that do not collapse at all: loop over the leading dims, batch the innermost one
             inner = batch_shape[-1]
             for idx in np.ndindex(*batch_shape[:-1]):
                 oa = _py.sum(i * s for i, s in zip(idx, sa[:-1])) * 4

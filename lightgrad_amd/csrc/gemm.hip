@@ -41,7 +41,9 @@ struct GemmArgs {
     float*       C;
     int64_t M, N, K;
     int64_t lda, ldb, ldc;
-    int64_t sA, sB, sC;     // batch strides (elements)
+    int64_t sA, sB, sC;     // batch strides (elements) of the outer batch index
+    int64_t sA2, sB2, sC2;  // ... of the inner batch index (batch = outer * batch_inner + inner; attention: (b, head))
+    int     batch_inner;    // >= 1
     int     tiles_m, tiles_n;
     int     nwg;            // tiles_m * tiles_n * batch * k_slices
     int     accumulate;
@@ -109,9 +111,10 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int gsize = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
     const int tm = first_m + (t % gspan) % gsize, tn = (t % gspan) / gsize;
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-    const float* __restrict__ A = g.A + int64_t(batch) * g.sA;
-    const float* __restrict__ B = g.B + int64_t(batch) * g.sB;
-    float* __restrict__ C = g.C + int64_t(batch) * g.sC;
+    const int b_outer = batch / g.batch_inner, b_inner = batch - b_outer * g.batch_inner;
+    const float* __restrict__ A = g.A + int64_t(b_outer) * g.sA + int64_t(b_inner) * g.sA2;
+    const float* __restrict__ B = g.B + int64_t(b_outer) * g.sB + int64_t(b_inner) * g.sB2;
+    float* __restrict__ C = g.C + int64_t(b_outer) * g.sC + int64_t(b_inner) * g.sC2;
     const int64_t ldc = g.ldc;
     const int accumulate = g.accumulate;
     const float* __restrict__ bias = g.bias;
@@ -551,7 +554,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      const float* A, int64_t lda, int64_t strideA,
                      const float* B, int64_t ldb, int64_t strideB,
                      float* C, int64_t ldc, int64_t strideC,
-                     int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0) {
+                     int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0,
+                     int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -570,8 +574,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
         }
         if (accumulate) return LG_OK;
         // empty sum: C = 0
-        int64_t shape[3] = {batch, M, N}, st[3] = {strideC, ldc, 1};
-        return lg_fill_strided(4, 3, shape, C, st, 0);
+        int64_t shape[4] = {batch / batch_inner, batch_inner, M, N}, st[4] = {strideC, strideC2, ldc, 1};
+        return lg_fill_strided(4, 4, shape, C, st, 0);
     }
 
     // operand tiles are addressed with 32-bit byte offsets from a per-tile descriptor base: the farthest element of a
@@ -589,6 +593,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.sA2 = strideA2; g.sB2 = strideB2; g.sC2 = strideC2;
+    g.batch_inner = int(batch_inner);
     g.accumulate = accumulate;
     g.bias = bias;
     g.rowsum = rowsum;
@@ -603,7 +609,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     auto vec_ok = [](const float* p, int64_t ld, int64_t bstride, int64_t contiguous_extent) {
         return aligned16(p) && ld % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0;
     };
-    const bool va = vec_ok(A, lda, strideA, akc ? K : M), vb = vec_ok(B, ldb, strideB, bkc ? K : N);
+    const bool va = vec_ok(A, lda, strideA, akc ? K : M) && strideA2 % 4 == 0, vb = vec_ok(B, ldb, strideB, bkc ? K : N) && strideB2 % 4 == 0;
 
     // tile choice: largest tile that still yields enough workgroups for 256 CUs
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
@@ -664,4 +670,15 @@ extern "C" int lg_gemm_rowsum_f32(int transA, int transB, int64_t M, int64_t N, 
                                   float* C, int64_t ldc, int accumulate, float* rowsum, int rowsum_accumulate) {
     LG_ARG(rowsum != nullptr, "lg_gemm_rowsum_f32: rowsum is NULL");
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, accumulate, nullptr, rowsum, rowsum_accumulate);
+}
+
+extern "C" int lg_gemm_batched2_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                    const float* A, int64_t lda, int64_t strideA_outer, int64_t strideA_inner,
+                                    const float* B, int64_t ldb, int64_t strideB_outer, int64_t strideB_inner,
+                                    float* C, int64_t ldc, int64_t strideC_outer, int64_t strideC_inner,
+                                    int64_t batch_outer, int64_t batch_inner, int accumulate) {
+    LG_ARG(batch_outer >= 0 && batch_inner >= 0 && batch_inner < (int64_t(1) << 30), "lg_gemm_batched2_f32: bad batch extents");
+    if (batch_outer == 0 || batch_inner == 0) return LG_OK;
+    return gemm_impl(transA, transB, M, N, K, A, lda, strideA_outer, B, ldb, strideB_outer, C, ldc, strideC_outer,
+                     batch_outer * batch_inner, accumulate, nullptr, nullptr, 0, batch_inner, strideA_inner, strideB_inner, strideC_inner);
 }

@@ -201,3 +201,23 @@ def test_long_vectors_and_wide_rows(hip):
     np.testing.assert_allclose(got, ref3, atol=1e-5 * n ** 0.5 * 4)
     outer = (ta.reshape(n, 1)[:70000] @ tb.reshape(1, n)[:, :5]).numpy()          # K = 1
     np.testing.assert_array_equal(outer, a[:70000, None] * b[None, :5])
+
+
+def test_attention_shaped_products_forward_backward(hip):
+    """(b, s, h, d) head split -> (b, h, s, d) views: scores = q @ k^T, context = p @ v and all four gradients go through
+    the two-level batched launch (lg_gemm_batched2_f32), including the column-major gradient of the k^T view"""
+    from lightgrad_amd import CpuTensor
+    rng = np.random.RandomState(12)
+    b, s, h, d = 3, 128, 2, 64
+    qn, kn, vn = (rng.uniform(-1, 1, (b, s, h * d)).astype(np.float32) for _ in range(3))
+    w = rng.uniform(-1, 1, (b, h, s, d)).astype(np.float32)
+    grads = {}
+    for cls in (CpuTensor, hip):
+        q, k, v = (cls.from_numpy(x) for x in (qn, kn, vn))
+        split = lambda t: t.reshape(b, s, h, d).transpose(0, 2, 1, 3)              # noqa: E731
+        scores = split(q) @ split(k).transpose(0, 1, 3, 2)
+        ctx = (scores * 0.125) @ split(v)
+        (ctx * cls.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        grads[cls] = [ctx.numpy()] + [t.grad.numpy() for t in (q, k, v)]
+    for got, ref, name in zip(grads[hip], grads[CpuTensor], ["ctx", "dq", "dk", "dv"]):
+        assert rel_err(got, ref.astype(np.float64)) <= 2e-5, name

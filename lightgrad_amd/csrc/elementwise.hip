@@ -325,6 +325,50 @@ __global__ void __launch_bounds__(256) ew_transposed_tile_v4(EwArgs a, IterDesc 
     }
 }
 
+// ---- dense 2-D outputs, any 2-D inputs ---------------------------------------------------
+// outputs (and the inputs flagged in dense_mask) are dense rows x cols and move as float4 over the FLAT index, whatever
+// cols is; the other inputs (row / column broadcasts, odd views) are fetched per element at row*s0 + col*s1.  This is
+// the bias add of a layer whose width is not a multiple of 4 ((1024, 30522) + (30522,): 2.6 -> 5 TB/s over the
+// per-element gather).
+template <class Op>
+__global__ void __launch_bounds__(256) ew_flat2d_vec4(EwArgs a, IterDesc d, int dense_mask, int64_t nvec) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= nvec) return;
+    const int64_t cols = d.shape[1], e0 = v * 4;
+    int64_t row = e0 / cols, col = e0 - row * cols;
+    float x[4][4];
+#pragma unroll
+    for (int i = 0; i < Op::NIN; ++i) {
+        if (a.in[i] == nullptr) {
+            x[i][0] = x[i][1] = x[i][2] = x[i][3] = a.scalar;
+        } else if ((dense_mask >> i) & 1) {
+            const float4 t = reinterpret_cast<const float4*>(a.in[i])[v];
+            x[i][0] = t.x; x[i][1] = t.y; x[i][2] = t.z; x[i][3] = t.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = 0; i < Op::NIN; ++i)
+            if (a.in[i] != nullptr && !((dense_mask >> i) & 1))
+                x[i][k] = a.in[i][row * d.stride[kInSlot + i][0] + col * d.stride[kInSlot + i][1]];
+        if (++col == cols) { col = 0; ++row; }
+    }
+    float y[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float in[4], out[2];
+#pragma unroll
+        for (int i = 0; i < Op::NIN; ++i) in[i] = x[i][k];
+        Op::apply(in, out);
+#pragma unroll
+        for (int o = 0; o < Op::NOUT; ++o) y[o][k] = out[o];
+    }
+#pragma unroll
+    for (int o = 0; o < Op::NOUT; ++o)
+        reinterpret_cast<float4*>(a.out[o])[v] = make_float4(y[o][0], y[o][1], y[o][2], y[o][3]);
+}
+
 // ---- host dispatch ----------------------------------------------------------------------------
 template <class Op>
 static int launch_ew(const EwArgs& args, const IterDesc& d) {
@@ -422,6 +466,23 @@ static int launch_ew(const EwArgs& args, const IterDesc& d) {
                                        tr_mask, int(tiles_r), int(tiles_c));
                 return LG_OK;
             }
+        }
+    }
+
+    // dense 2-D outputs with broadcast / strided 2-D inputs
+    if (nd == 2 && d.numel % 4 == 0 && d.numel / 4 < (int64_t(1) << 31) * 256) {
+        bool ok = true;
+        int dense_mask = 0;
+        for (int o = 0; o < nslots_out; ++o)
+            ok = ok && d.stride[kOutSlot + o][1] == 1 && d.stride[kOutSlot + o][0] == d.shape[1] && aligned16(args.out[o]);
+        for (int i = 0; i < nslots_in && ok; ++i) {
+            if (!args.in[i]) continue;
+            if (d.stride[kInSlot + i][1] == 1 && d.stride[kInSlot + i][0] == d.shape[1] && aligned16(args.in[i])) dense_mask |= 1 << i;
+        }
+        if (ok) {
+            const int64_t nvec = d.numel / 4;
+            hipLaunchKernelGGL((ew_flat2d_vec4<Op>), dim3(unsigned((nvec + 255) / 256)), dim3(256), 0, s, args, d, dense_mask, nvec);
+            return LG_OK;
         }
     }
 

@@ -276,6 +276,29 @@ def test_transposed_operand_tiles(hip, shape):
         np.testing.assert_array_equal((ta[:-4, 4:] + tbt[4:, :-4].transpose(1, 0)).numpy(), a[:-4, 4:] + bt[4:, :-4].T)
 
 
+@pytest.mark.parametrize("shape", [(1024, 30522), (36, 10), (4, 7), (128, 513), (2, 3, 5, 26)])
+def test_dense_outputs_with_odd_inner_width(hip, shape):
+    """row / column broadcasts and two-output backward forms when the inner width is not a multiple of 4 (the float4
+    flat-2D path): bias add of the BERT decoder (1024, 30522) + (30522,), the MLP's (1024, 10) + (10,) shape class"""
+    rng = np.random.RandomState(4)
+    a = rng.uniform(-1, 1, shape).astype(np.float32)
+    row = rng.uniform(-1, 1, shape[-1:]).astype(np.float32)
+    col = rng.uniform(-1, 1, shape[:-1] + (1,)).astype(np.float32)
+    ta, trow, tcol = hip.from_numpy(a), hip.from_numpy(row), hip.from_numpy(col)
+    np.testing.assert_array_equal((ta + trow).numpy(), a + row)
+    np.testing.assert_array_equal((tcol * ta).numpy(), col * a)
+    np.testing.assert_array_equal((trow - tcol).numpy(), row - col)               # both operands broadcast
+    y = ta * trow
+    (y * tcol).backward(allow_fill=True)
+    np.testing.assert_array_equal(ta.grad.numpy(), col * row * np.ones_like(a))
+    np.testing.assert_allclose(trow.grad.numpy(), (col * a).reshape(-1, shape[-1]).astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    with light.no_grad():
+        acc = hip.from_numpy(a.copy())
+        acc += trow
+        acc *= tcol
+    np.testing.assert_array_equal(acc.numpy(), (a + row) * col)
+
+
 def test_reductions_full_size(hip):
     rng = np.random.RandomState(1)
     n = 4096

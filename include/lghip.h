@@ -79,6 +79,14 @@ int lg_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* stream-ordered
 /* upload without waiting: src is staged into pinned memory (reusable on return), the DMA is stream-ordered.
  * Feeds a new batch into the static input tensor of a captured graph between two lg_graph_launch calls. */
 int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes);
+/* The same upload split in two so that it overlaps with compute: lg_prefetch_h2d starts the DMA of the NEXT batch on
+ * a copy stream into a device staging slot (pinned sources - lg_host_malloc - are read in place, pageable ones are
+ * staged first) and returns a slot id; lg_prefetch_commit makes the library's stream wait for that DMA and copies the
+ * slot into `dst` device to device.  A step then costs max(DMA, compute), not their sum. */
+int lg_host_malloc(void** ptr, size_t bytes);              /* pinned host memory */
+int lg_host_free(void* ptr);
+int lg_prefetch_h2d(const void* src, size_t bytes, int* slot);
+int lg_prefetch_commit(int slot, void* dst, size_t bytes);
 
 /* HIP events on the library's stream (timing in bench.py) */
 int lg_event_create(void** ev);

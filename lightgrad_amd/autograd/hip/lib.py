@@ -47,6 +47,10 @@ PROTOTYPES = {
     "lg_pool_stats": (c_int, [POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     "lg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "lg_host_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "lg_host_free": (c_int, [c_void_p]),
+    "lg_prefetch_h2d": (c_int, [c_void_p, c_size_t, POINTER(c_int)]),
+    "lg_prefetch_commit": (c_int, [c_int, c_void_p, c_size_t]),
     "lg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_event_create": (c_int, [POINTER(c_void_p)]),

@@ -43,6 +43,14 @@ class HipBuffer(object):
             _l._lib.lg_free(ptr)
 
 
+class PendingUpload(object):
+    """a host array on its way to a device staging slot (HipTensor.prefetch); consumed by HipTensor.commit_"""
+    __slots__ = ("slot", "shape", "dtype", "nbytes", "keepalive")
+
+    def __init__(self, slot, shape, dtype, nbytes, keepalive):
+        self.slot, self.shape, self.dtype, self.nbytes, self.keepalive = slot, tuple(shape), np.dtype(dtype), nbytes, keepalive
+
+
 class HipDevice(object):
     """The GPU this process is bound to (one process per GPU; reference analog: OpenCLDevice,
     opencl/device.py:68-115 - context + in-order queue + memory pool)."""
@@ -66,6 +74,19 @@ class HipDevice(object):
     @staticmethod
     def synchronize() -> None:
         _l.check(_l.lib().lg_sync())
+
+    @staticmethod
+    def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+        """numpy array in pinned (page-locked) host memory: the DMA engine reads it in place, so `HipTensor.prefetch` /
+        `upload_` of such an array involve no host-side staging copy.  Freed when the array (and its views) die."""
+        import weakref
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr = ctypes.c_void_p()
+        _l.check(_l.lib().lg_host_malloc(ctypes.byref(ptr), max(nbytes, 1)))
+        raw = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
+        weakref.finalize(raw, _l._lib.lg_host_free, ptr)
+        return np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
 
     @staticmethod
     def pool_stats() -> dict:
@@ -194,6 +215,27 @@ class HipTensor(AbstractTensor):
             a = a.copy(order="C")
         if a.nbytes > 0:
             _l.check(_l.lib().lg_memcpy_h2d_async(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    @staticmethod
+    def prefetch(a: np.ndarray) -> "PendingUpload":
+        """start copying a host array to the device on the COPY stream and return at once; `tensor.commit_(pending)`
+        later makes the compute stream wait for that DMA and moves the data into `tensor`.  Prefetching batch i+1
+        before replaying the step on batch i overlaps the PCIe transfer with compute (examples/mnist.py --graph)."""
+        a = np.asarray(a)
+        if not a.flags["C_CONTIGUOUS"]:
+            a = a.copy(order="C")
+        assert a.nbytes > 0
+        slot = ctypes.c_int(-1)
+        _l.check(_l.lib().lg_prefetch_h2d(a.ctypes.data, a.nbytes, ctypes.byref(slot)))
+        return PendingUpload(slot.value, a.shape, a.dtype, a.nbytes, a)
+
+    def commit_(self, pending: "PendingUpload") -> "HipTensor":
+        assert self.is_contiguous() and pending.shape == self._shape and pending.dtype == self._dtype, \
+            "commit_: need a dense tensor of shape %s / dtype %s" % (pending.shape, pending.dtype)
+        assert pending.slot >= 0, "this prefetch has already been committed"
+        _l.check(_l.lib().lg_prefetch_commit(pending.slot, self.ptr, pending.nbytes))
+        pending.slot, pending.keepalive = -1, None
         return self
 
     def is_contiguous(self) -> bool:

@@ -304,6 +304,114 @@ int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes) {
     return LG_OK;
 }
 
+// ---- prefetch on a copy stream ---------------------------------------------------------------------------------
+// The DMA of the NEXT batch runs on its own stream while the compute stream replays the current step:
+//   lg_prefetch_h2d   host -> a device staging slot, on the copy stream (pinned sources are read in place)
+//   lg_prefetch_commit   compute stream waits for that DMA, copies slot -> dst (device to device, microseconds) and
+//                        frees the slot for the next prefetch
+// so a step costs max(DMA, compute) instead of their sum.
+namespace {
+struct PrefetchSlot {
+    void*      dev = nullptr;
+    size_t     capacity = 0, bytes = 0;
+    hipEvent_t copied = nullptr, consumed = nullptr;
+    bool       in_flight = false, consumed_recorded = false;
+};
+constexpr int kPrefetchSlots = 4;
+PrefetchSlot g_prefetch[kPrefetchSlots];
+int g_prefetch_next = 0;
+hipStream_t g_copy_stream = nullptr;
+}  // namespace
+
+int lg_host_malloc(void** ptr, size_t bytes) {
+    LG_REQUIRE_INIT();
+    LG_ARG(ptr != nullptr, "lg_host_malloc: NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return LG_OK;
+    LG_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return LG_OK;
+}
+
+int lg_host_free(void* ptr) {
+    LG_REQUIRE_INIT();
+    if (ptr) LG_HIP(hipHostFree(ptr));
+    return LG_OK;
+}
+
+int lg_prefetch_h2d(const void* src, size_t bytes, int* slot_out) {
+    LG_REQUIRE_INIT();
+    LG_ARG(src != nullptr && slot_out != nullptr && bytes > 0, "lg_prefetch_h2d: bad arguments");
+    if (!g_copy_stream) LG_HIP(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
+    const int slot = g_prefetch_next;
+    PrefetchSlot& ps = g_prefetch[slot];
+    LG_ARG(!ps.in_flight, "lg_prefetch_h2d: all %d prefetch slots are waiting for lg_prefetch_commit", kPrefetchSlots);
+    g_prefetch_next = (g_prefetch_next + 1) % kPrefetchSlots;
+    if (!ps.copied) {
+        LG_HIP(hipEventCreateWithFlags(&ps.copied, hipEventDisableTiming));
+        LG_HIP(hipEventCreateWithFlags(&ps.consumed, hipEventDisableTiming));
+    }
+    if (ps.consumed_recorded) {
+        if (ps.capacity < bytes) LG_HIP(hipEventSynchronize(ps.consumed));      // about to free the buffer
+        else LG_HIP(hipStreamWaitEvent(g_copy_stream, ps.consumed, 0));          // the copy stream waits, not the host
+    }
+    if (ps.capacity < bytes) {
+        if (ps.dev) LG_HIP(hipFree(ps.dev));
+        ps.dev = nullptr;
+        ps.capacity = 0;
+        const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+        LG_HIP(hipMalloc(&ps.dev, want));
+        ps.capacity = want;
+    }
+    // pinned sources are read by the DMA engine in place; pageable ones go through the pinned staging ring
+    hipPointerAttribute_t attr;
+    const void* dma_src = src;
+    const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned) {
+        (void)hipGetLastError();
+        Staging& st = g_staging[g_staging_next];
+        g_staging_next = (g_staging_next + 1) % kStagingSlots;
+        if (st.busy) {
+            LG_HIP(hipEventSynchronize(st.done));
+            st.busy = false;
+        }
+        if (st.bytes < bytes) {
+            if (st.host) LG_HIP(hipHostFree(st.host));
+            st.host = nullptr;
+            st.bytes = 0;
+            const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+            LG_HIP(hipHostMalloc(&st.host, want, hipHostMallocDefault));
+            st.bytes = want;
+        }
+        if (!st.done) LG_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        memcpy(st.host, src, bytes);
+        dma_src = st.host;
+        LG_HIP(hipMemcpyAsync(ps.dev, dma_src, bytes, hipMemcpyHostToDevice, g_copy_stream));
+        LG_HIP(hipEventRecord(st.done, g_copy_stream));
+        st.busy = true;
+    } else {
+        LG_HIP(hipMemcpyAsync(ps.dev, dma_src, bytes, hipMemcpyHostToDevice, g_copy_stream));
+    }
+    LG_HIP(hipEventRecord(ps.copied, g_copy_stream));
+    ps.bytes = bytes;
+    ps.in_flight = true;
+    *slot_out = slot;
+    return LG_OK;
+}
+
+int lg_prefetch_commit(int slot, void* dst, size_t bytes) {
+    LG_REQUIRE_INIT();
+    LG_ARG(slot >= 0 && slot < kPrefetchSlots && dst != nullptr, "lg_prefetch_commit: bad slot / destination");
+    LG_ARG(!capturing(), "lg_prefetch_commit: not allowed while capturing a graph (commit between graph launches)");
+    PrefetchSlot& ps = g_prefetch[slot];
+    LG_ARG(ps.in_flight && ps.bytes == bytes, "lg_prefetch_commit: slot %d holds no prefetch of %zu bytes", slot, bytes);
+    LG_HIP(hipStreamWaitEvent(rt().stream, ps.copied, 0));
+    LG_HIP(hipMemcpyAsync(dst, ps.dev, bytes, hipMemcpyDeviceToDevice, rt().stream));
+    LG_HIP(hipEventRecord(ps.consumed, rt().stream));
+    ps.consumed_recorded = true;
+    ps.in_flight = false;
+    return LG_OK;
+}
+
 int lg_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     LG_REQUIRE_INIT();
     if (bytes == 0) return LG_OK;

@@ -1,1 +1,1 @@
-for t in 2 0 9; do echo "tile=$t"; LG_GEMM_TILE=$t python tools/gemm_probe.py 1024,30522,128,0,1 1024,128,30522,0,0 30522,128,1024,1,0 128,30522,1024,1,0 1024,512,128,0,1 1024,128,512,0,1 1024,128,128,0,1; done
+python tools/hbm_bench.py 2>&1 | grep -E "sum|max|kernel"

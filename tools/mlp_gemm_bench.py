@@ -51,4 +51,4 @@ for name, fn in cases.items():
     us = timed(fn)
     total += us
     print("%-44s %7.2f us" % (name, us))
-print("knobs: MID=%s TARGET_WGS=%s   total %.1f us" % (os.environ.get("LG_GEMM_MID", "0"), os.environ.get("LG_GEMM_TARGET_WGS", "512"), total))
+print("knobs: LG_GEMM_TILE=%s LG_GEMM_SLICES=%s   total %.1f us" % (os.environ.get("LG_GEMM_TILE", "auto"), os.environ.get("LG_GEMM_SLICES", "auto"), total))

@@ -190,7 +190,10 @@ int lg_reduce_acc(int op, int ndim, const int64_t* shape,
  * (opencl/kernels.py:291-298, :319-320, :331).
  * batch > 1: operand b starts at base + b*stride{A,B,C} elements (stride 0
  * broadcasts an operand over the batch).  accumulate != 0 adds into C.
- * replaces kernels.dot (opencl/kernels.py:201-337) called from opencl/ops.py:116-132. */
+ * replaces kernels.dot (opencl/kernels.py:201-337) called from opencl/ops.py:116-132.  * Operands are fetched in 16-byte pieces along their contiguous index: when that extent is not a multiple of 4, up to
+ * 12 bytes behind an operand's last row are READ (never used).  Memory from lg_malloc always has them; foreign
+ * memory passed here must be readable that far.
+ */
 int lg_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const float* A, int64_t lda, int64_t strideA,
                 const float* B, int64_t ldb, int64_t strideB,
@@ -274,6 +277,10 @@ int lg_layernorm_f32(const float* x, const float* w, const float* b, float* y, f
                      int64_t rows, int64_t cols, double eps);
 int lg_layernorm_bwd_f32(const float* g, const float* w, const float* xhat, const float* rstd, float* dx,
                          int64_t rows, int64_t cols);
+/* parameter gradients of the same LayerNorm from one launch: dw[c] (+)= sum_r g[r][c] * xhat[r][c], db[c] (+)= sum_r g[r][c]
+ * (the tape's mul + two un-broadcasting column sums of func.py:50-56 + two `grad +=`) */
+int lg_layernorm_param_grads_f32(const float* g, const float* xhat, float* dw, float* db, int64_t rows, int64_t cols,
+                                 int dw_accumulate, int db_accumulate);
 /* embedding lookup out[i, :] = table[ids[i], :] (ids int32 or int64, negative ids wrap like numpy) and its
  * gradient grad_table[ids[i], :] += grad_out[i, :] (float atomics: repeated ids ACCUMULATE; the reference's
  * numpy `grad[idx] = g`, cpu/ops.py:245, keeps only the last one, and its BERT example drops the gradient). */

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),
     "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_cross_entropy_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_layernorm_param_grads_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int]),
     "lg_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
     "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
 }

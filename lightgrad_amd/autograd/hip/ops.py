@@ -595,7 +595,16 @@ class getitem(Function):
     def backward(ctx, out_grad):
         shape, idx = ctx.get_saved_tensors()
         if isinstance(idx, HipTensor):
-            return _scatter_add_rows(shape, idx, out_grad)      # repeated ids accumulate
+            # repeated ids accumulate.  A leaf table that already owns a gradient buffer (an embedding matrix after
+            # zero_grad) gets the rows added in place: no table-sized zero fill, no table-sized `grad +=`
+            table = ctx._parents[0]
+            acc = table._grad_accumulator() if table.requires_grad else None
+            if acc is not None and acc.is_contiguous() and acc._dtype == _F32:
+                if table._consume_zero_pending():
+                    acc.fill(0)
+                _scatter_add_rows(shape, idx, out_grad, into=acc)
+                return None
+            return _scatter_add_rows(shape, idx, out_grad)
         grad = HipTensor.zeros(shape, dtype=out_grad._dtype, requires_grad=False)
         grad[idx] = out_grad
         return grad
@@ -895,11 +904,20 @@ class layer_norm(Function):
         g = out_grad.contiguous()
         dx = HipTensor.empty(xhat._shape)
         _l.check(_l.lib().lg_layernorm_bwd_f32(g.ptr, w.ptr, xhat.ptr, rstd.ptr, dx.ptr, rows, cols))
-        g2 = HipTensor(g.data, (rows, cols), None, g._offset, g._dtype)
-        h2 = HipTensor(xhat.data, (rows, cols), None, xhat._offset, xhat._dtype)
-        dw = _reduce(_l.RED_SUM, _binary(_l.EW_MUL, g2, h2), (0,), False)
-        db = _reduce(_l.RED_SUM, g2, (0,), False)
-        return dx, dw, db
+        # dw = sum_rows(g * xhat), db = sum_rows(g) from one launch, added straight into the parameters' gradient buffers
+        # when they have one (leaf parameters after zero_grad), like linear.backward does
+        weight, bias = ctx._parents[1], ctx._parents[2]
+        acc_w = weight._grad_accumulator() if weight.requires_grad else None
+        acc_b = bias._grad_accumulator() if bias.requires_grad else None
+        acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+        acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+        dw = acc_w if acc_w is not None else HipTensor.empty((cols,))
+        db = acc_b if acc_b is not None else HipTensor.empty((cols,))
+        _l.check(_l.lib().lg_layernorm_param_grads_f32(
+            g.ptr, xhat.ptr, dw.ptr, db.ptr, rows, cols,
+            1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
+            1 if (acc_b is not None and not bias._consume_zero_pending()) else 0))
+        return dx, (None if acc_w is not None else dw), (None if acc_b is not None else db)
 
 
 def _gather_rows(table, ids):
@@ -915,8 +933,8 @@ def _gather_rows(table, ids):
     return out
 
 
-def _scatter_add_rows(shape, ids, out_grad):
-    grad = HipTensor.zeros(shape, requires_grad=False)
+def _scatter_add_rows(shape, ids, out_grad, into=None):
+    grad = into if into is not None else HipTensor.zeros(shape, requires_grad=False)
     ids, g = ids.contiguous(), out_grad.contiguous()
     row_len = 1
     for s in shape[1:]:

@@ -60,6 +60,7 @@ struct GemmArgs {
     // of C against a VIRTUAL column of ones appended to op(B) - the tiling, split-K and fold treat it like any column
     float*  rowsum;         // [M] or NULL
     int     rowsum_accumulate;
+    int     k_tail;         // K % 4 != 0: K-contiguous float4s of the last tile carry elements beyond K, zeroed before LDS
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -176,11 +177,22 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         d[0] = unsigned(p); d[1] = unsigned(p >> 32) & 0xffffu; d[2] = OOB; d[3] = 0x00020000u;
         return d;
     };
-    auto load_tile = [&](int64_t k0, int slot) {
-        const int krem = int(k_end - k0 < BK ? k_end - k0 : BK);     // k values of this tile inside the slice
+    // tiles are requested strictly in order: running pointers instead of index arithmetic (every scalar instruction in
+    // the K loop of a lone small-tile workgroup shows up in its time)
+    const float* nextA = AKC ? Atile0 + k_begin : Atile0 + k_begin * g.lda;
+    const float* nextB = BKC ? Btile0 + k_begin : Btile0 + k_begin * g.ldb;
+    const int64_t stepA = AKC ? int64_t(BK) : int64_t(BK) * g.lda, stepB = BKC ? int64_t(BK) : int64_t(BK) * g.ldb;
+    const int nkt = int((k_end - k_begin + BK - 1) / BK);           // K-tiles of this slice (32-bit: scalar compares in the loop)
+    const int last_krem = int(k_end - k_begin) - (nkt - 1) * BK;     // k values of the last one
+    int requested = 0;
+    auto load_tile = [&](int slot) {
+        const int krem = requested == nkt - 1 ? last_krem : BK;      // k values of this tile inside the slice
+        ++requested;
         krem_ring[slot] = krem;
-        const u32x4 da = descriptor(AKC ? Atile0 + k0 : Atile0 + k0 * g.lda);
-        const u32x4 db = descriptor(BKC ? Btile0 + k0 : Btile0 + k0 * g.ldb);
+        const u32x4 da = descriptor(nextA);
+        const u32x4 db = descriptor(nextB);
+        nextA += stepA;
+        nextB += stepB;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const unsigned off = kcA[i] < krem ? offA[i] : OOB;
@@ -208,6 +220,25 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     auto store_tile = [&](int buf, int slot) {
         float* a = lds + buf * BUF;
         float* b = lds + buf * BUF + A_TILE;
+        // K not a multiple of 4: the last float4 of a K-contiguous row runs into the next row - zero what lies beyond the
+        // slice (only the slice's last tile can be short)
+        if (g.k_tail && krem_ring[slot] < BK) {
+            asm volatile("; short K tail" ::: "memory");        // keeps this rare fix-up a branch, not selects in every iteration
+            if constexpr (VA && AKC) {
+#pragma unroll
+                for (int i = 0; i < A_CHUNKS; ++i)
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (kcA[i] + e >= krem_ring[slot]) ra_ring[slot][i][e] = 0.f;
+            }
+            if constexpr (VB && BKC) {
+#pragma unroll
+                for (int i = 0; i < B_CHUNKS; ++i)
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (kcB[i] + e >= krem_ring[slot]) rb_ring[slot][i][e] = 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int f = tid + i * NT;
@@ -226,7 +257,12 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 const bool virt = (virt_mask >> i) & 1u, kv = kcB[i] < krem_ring[slot];
                 const float one = kv ? 1.0f : 0.0f;
                 if constexpr (VB) {
-                    if constexpr (BKC) { if (virt) rb_ring[slot][i] = f32x4{one, one, one, one}; }      // row N of B^T: ones along k
+                    if constexpr (BKC) {                                                           // row N of B^T: ones along k
+                        if (virt) {
+                            const int kr = krem_ring[slot] - kcB[i];
+                            rb_ring[slot][i] = f32x4{kr > 0 ? 1.f : 0.f, kr > 1 ? 1.f : 0.f, kr > 2 ? 1.f : 0.f, kr > 3 ? 1.f : 0.f};
+                        }
+                    }
                     else               { if (virt) rb_ring[slot][i] = f32x4{one, 0.f, 0.f, 0.f}; }     // k-row of B: column N, then beyond
                 } else {
                     if (virt) rb_ring[slot][i] = one;
@@ -290,14 +326,13 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         }
     };
 
-    const int64_t nkt = (k_end - k_begin + BK - 1) / BK;
     // tile j waits in ring slot j % PD; tiles 0 .. PD-1 are requested up front
 #pragma unroll
     for (int u = 0; u < PD; ++u)
-        if (u < nkt) load_tile(k_begin + u * BK, u);
+        if (u < nkt) load_tile(u);
     {
-        const int64_t younger = nkt - 1 < PD - 1 ? nkt - 1 : PD - 1;
-        wait_tile(0, int(younger));
+        const int younger = nkt - 1 < PD - 1 ? nkt - 1 : PD - 1;
+        wait_tile(0, younger);
     }
     store_tile(0, 0);
     __syncthreads();
@@ -338,22 +373,22 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][q][e], fb[slot][q][e], acc[0][0], 0, 0, 0);
         };
         read_half(0, 0, 0);
-        for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+        for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int64_t kt = kt0 + u;
+                const int kt = kt0 + u;
                 if (kt < nkt) {
-                    const int cur = int(kt & 1);
-                    if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
+                    const int cur = kt & 1;
+                    if (PD == 1 && kt + 1 < nkt) load_tile(0);
                     read_half(cur, 1, 1);
                     mfma_half(0);
                     if (kt + 1 < nkt) {
-                        int64_t younger = nkt - (kt + 2);
+                        int younger = nkt - (kt + 2);
                         if (younger > PD - 2) younger = PD - 2;
-                        wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
+                        wait_tile((u + 1) % PD, PD == 1 ? 0 : (younger < 0 ? 0 : younger));
                         store_tile(cur ^ 1, (u + 1) % PD);
                     }
-                    if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
+                    if (PD > 1 && kt + PD < nkt) load_tile(u);
                     __syncthreads();
                     if (kt + 1 < nkt) read_half(cur ^ 1, 0, 0);
                     mfma_half(1);
@@ -361,24 +396,24 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             }
         }
     } else {
-        for (int64_t kt0 = 0; kt0 < nkt; kt0 += PD) {
+        for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
     #pragma unroll
             for (int u = 0; u < PD; ++u) {
-                const int64_t kt = kt0 + u;
+                const int kt = kt0 + u;
                 if (kt < nkt) {
-                    const int cur = int(kt & 1);
+                    const int cur = kt & 1;
                     // PD == 1: tile kt+1 is requested here and written to LDS in the middle of this iteration.
                     // PD  > 1: slot u (tile kt, in LDS since the last iteration) is refilled with tile kt + PD below, after
                     //          the LDS write of tile kt+1 - whose loads were requested PD-1 iterations ago.
-                    if (PD == 1 && kt + 1 < nkt) load_tile(k_begin + (kt + 1) * BK, 0);
+                    if (PD == 1 && kt + 1 < nkt) load_tile(0);
                     compute_tile(cur, 0, BK / 2);
                     if (kt + 1 < nkt) {
-                        int64_t younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
+                        int younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
                         if (younger > PD - 2) younger = PD - 2;
-                        wait_tile((u + 1) % PD, PD == 1 ? 0 : int(younger < 0 ? 0 : younger));
+                        wait_tile((u + 1) % PD, PD == 1 ? 0 : (younger < 0 ? 0 : younger));
                         store_tile(cur ^ 1, (u + 1) % PD);                // ds_writes issue in the shadow of the second half's MFMAs
                     }
-                    if (PD > 1 && kt + PD < nkt) load_tile(k_begin + (kt + PD) * BK, u);
+                    if (PD > 1 && kt + PD < nkt) load_tile(u);
                     compute_tile(cur, BK / 2, BK);
                     __syncthreads();
                 }
@@ -599,17 +634,21 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.bias = bias;
     g.rowsum = rowsum;
     g.rowsum_accumulate = rowsum_accumulate;
+    g.k_tail = (K % 4 != 0) ? 1 : 0;
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
     if (g.group_m < 1) g.group_m = 1;
 
     const bool akc = !transA;   // A[m*lda + k]: k is the contiguous index
     const bool bkc = transB != 0;   // B[n*ldb + k]
-    // float4 staging needs 16-byte aligned rows and whole float4s inside the matrix
-    auto vec_ok = [](const float* p, int64_t ld, int64_t bstride, int64_t contiguous_extent) {
-        return aligned16(p) && ld % 4 == 0 && bstride % 4 == 0 && contiguous_extent % 4 == 0;
-    };
-    const bool va = vec_ok(A, lda, strideA, akc ? K : M) && strideA2 % 4 == 0, vb = vec_ok(B, ldb, strideB, bkc ? K : N) && strideB2 % 4 == 0;
+    // float4 staging: buffer loads of 4 dwords need dword alignment only, and a float4 that runs past the contiguous
+    // extent is harmless: rows / columns beyond M / N are never stored, k beyond K is zeroed before it reaches LDS, and
+    // the up to 12 bytes it may read behind the operand's last row exist (lg_malloc pads every block by 16 bytes; memory
+    // from elsewhere must be readable that far - include/lghip.h).  The one exception: the virtual ones-column must start
+    // a float4 of its own.
+    const bool va = true;
+    const bool vb = (rowsum == nullptr) || bkc || N % 4 == 0;
+    (void)strideA2; (void)strideB2;
 
     // tile choice: largest tile that still yields enough workgroups for 256 CUs
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };

@@ -135,6 +135,74 @@ __global__ void __launch_bounds__(256) layernorm_bwd(const float* __restrict__ g
     for (int64_t c = lane; c < cols; c += 64) dx[row * cols + c] = r * (gr[c] * w[c] - s1 - hr[c] * s2);
 }
 
+// ---- LayerNorm parameter gradients: dw[c] = sum_r g[r][c] * xhat[r][c], db[c] = sum_r g[r][c] -------------------
+// one thread per column (coalesced along the row), the rows split over blockIdx.y; with more than one split the
+// partial sums are published write-through, a per-column-block ticket elects the last workgroup, which folds them in
+// split order (cdna_hip_programming.md, in-launch split-K recipe).  Replaces mul + two column sums + two adds.
+__global__ void __launch_bounds__(256) layernorm_param_grads(const float* __restrict__ g, const float* __restrict__ xhat,
+                                                             float* dw, float* db, float* partial, int* tickets,
+                                                             int64_t rows, int64_t cols, int64_t chunk, int acc_w, int acc_b) {
+    const int64_t c_raw = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const bool live = c_raw < cols;
+    const int64_t c = live ? c_raw : cols - 1;
+    const int64_t split = blockIdx.y, splits = gridDim.y;
+    const int64_t r0 = split * chunk;
+    const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gv = g[(r + e) * cols + c], hv = xhat[(r + e) * cols + c];
+            sw[e] += gv * hv;
+            sb[e] += gv;
+        }
+    }
+    for (; r < r1; ++r) {
+        const float gv = g[r * cols + c];
+        sw[0] += gv * xhat[r * cols + c];
+        sb[0] += gv;
+    }
+    float vw = (sw[0] + sw[1]) + (sw[2] + sw[3]), vb = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+    if (splits > 1) {
+        __hip_atomic_store(partial + (split * 2 + 0) * cols + c, vw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partial + (split * 2 + 1) * cols + c, vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int arrived_last;
+        if (threadIdx.x == 0) {
+            int* ticket = tickets + blockIdx.x;
+            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = order == int(splits) - 1;
+            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived_last = last;
+        }
+        __syncthreads();
+        if (!arrived_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        vw = vb = 0.f;
+        int64_t s0 = 0;
+        for (; s0 + 3 < splits; s0 += 4) {
+            float xw[4], xb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xw[e] = __hip_atomic_load(partial + ((s0 + e) * 2 + 0) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xb[e] = __hip_atomic_load(partial + ((s0 + e) * 2 + 1) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vw += xw[e]; vb += xb[e]; }
+        }
+        for (; s0 < splits; ++s0) {
+            vw += __hip_atomic_load(partial + (s0 * 2 + 0) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vb += __hip_atomic_load(partial + (s0 * 2 + 1) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (live) {
+        dw[c] = acc_w ? dw[c] + vw : vw;
+        db[c] = acc_b ? db[c] + vb : vb;
+    }
+}
+
 // ---- cross entropy of softmax(logits) against integer labels (reference loss.py:14-24) ------------------------
 // one wave per row: p = softmax(row); nll[row] = -log(p[label]); d[row][c] = (p[c] - [c == label]) / rows
 template <typename LabelT>
@@ -156,6 +224,53 @@ __global__ void __launch_bounds__(256) cross_entropy_rows(const float* __restric
     if (label < 0) label += cols;
     for (int64_t c = lane; c < cols; c += 64) {
         const float p = expf(xr[c] + (-m)) * inv;
+        dlogits[row * cols + c] = (c == label ? p - 1.0f : p) * inv_rows;
+        if (c == label) nll[row] = -logf(p);
+    }
+}
+
+// wide rows (a vocabulary): one WORKGROUP per row.  Pass 1 keeps a running (max, sum of exp) per thread over coalesced
+// loads, combined across the workgroup; pass 2 re-reads the row (L2 / Infinity Cache) and writes the gradient.
+template <typename LabelT>
+__global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restrict__ x, const LabelT* __restrict__ labels,
+                                                          float* __restrict__ dlogits, float* __restrict__ nll, int64_t cols,
+                                                          float inv_rows) {
+    __shared__ float red_m[4], red_s[4];
+    const int64_t row = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xr = x + row * cols;
+    float m = -INFINITY, sum = 0.f;
+    auto absorb = [&](float t) {
+        if (t > m || t != t) {                       // new maximum (NaN propagates like np.max): rescale the running sum
+            sum = sum * expf(m - t) + 1.0f;
+            m = t;
+        } else if (t != -INFINITY) {                 // (-inf) - (-inf) would be NaN; exp(-inf - m) is 0 anyway
+            sum += expf(t - m);
+        }
+    };
+    int64_t c = threadIdx.x;
+    for (; c + 768 < cols; c += 1024) {
+        const float t0 = xr[c], t1 = xr[c + 256], t2 = xr[c + 512], t3 = xr[c + 768];
+        absorb(t0); absorb(t1); absorb(t2); absorb(t3);
+    }
+    for (; c < cols; c += 256) absorb(xr[c]);
+    // combine (m, sum) pairs: wave, then the four waves
+    const float wm = wave_max(m);
+    sum = (m == -INFINITY && wm == -INFINITY) ? 0.f : sum * expf(m - wm);
+    sum = wave_sum(sum);
+    if (lane == 0) { red_m[wave] = wm; red_s[wave] = sum; }
+    __syncthreads();
+    float M = red_m[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = (red_m[w] > M || red_m[w] != red_m[w]) ? red_m[w] : M;
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) S += (red_m[w] == -INFINITY && M == -INFINITY) ? 0.f : red_s[w] * expf(red_m[w] - M);
+    const float inv = 1.0f / S;
+    int64_t label = int64_t(labels[row]);
+    if (label < 0) label += cols;
+    for (c = threadIdx.x; c < cols; c += 256) {
+        const float p = expf(xr[c] + (-M)) * inv;
         dlogits[row * cols + c] = (c == label ? p - 1.0f : p) * inv_rows;
         if (c == label) nll[row] = -logf(p);
     }
@@ -283,6 +398,17 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     const dim3 grid(unsigned((rows + 3) / 4)), block(256);
     const float inv_rows = float(1.0 / double(rows));
     hipStream_t s = rt().stream;
+    if (cols >= 4096 && rows < (int64_t(1) << 31)) {       // a vocabulary per row: one workgroup per row
+        const dim3 wgrid{unsigned(rows)};
+        if (label_itemsize == 2)
+            hipLaunchKernelGGL(cross_entropy_wide<int16_t>, wgrid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, cols, inv_rows);
+        else if (label_itemsize == 4)
+            hipLaunchKernelGGL(cross_entropy_wide<int32_t>, wgrid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, cols, inv_rows);
+        else
+            hipLaunchKernelGGL(cross_entropy_wide<int64_t>, wgrid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, cols, inv_rows);
+        LG_CHECK_LAUNCH();
+        return LG_OK;
+    }
     if (label_itemsize == 2)
         hipLaunchKernelGGL(cross_entropy_rows<int16_t>, grid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
     else if (label_itemsize == 4)
@@ -291,4 +417,32 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
         hipLaunchKernelGGL(cross_entropy_rows<int64_t>, grid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows);
     LG_CHECK_LAUNCH();
     return LG_OK;
+}
+
+extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, float* dw, float* db, int64_t rows, int64_t cols,
+                                            int dw_accumulate, int db_accumulate) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_layernorm_param_grads_f32: bad shape");
+    LG_ARG(g && xhat && dw && db, "lg_layernorm_param_grads_f32: NULL pointer");
+    const int64_t blocks_x = (cols + 255) / 256;
+    LG_ARG(blocks_x < (int64_t(1) << 31), "lg_layernorm_param_grads_f32: too many columns");
+    int64_t splits = 1;
+    if (rows >= 64) {
+        splits = 512 / blocks_x;                               // enough workgroups to fill the chip ...
+        if (splits * 16 > rows) splits = rows / 16;            // ... with at least 16 rows each
+        if (splits > 32) splits = 32;                          // ... and a short fold
+        if (splits < 1) splits = 1;
+        if (blocks_x > rt().n_gemm_tickets) splits = 1;
+    }
+    const int64_t chunk = rows > 0 ? (rows + splits - 1) / splits : 1;
+    splits = rows > 0 ? (rows + chunk - 1) / chunk : 1;
+    float* partial = nullptr;
+    if (splits > 1) {
+        int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(splits * 2 * cols) * sizeof(float));
+        if (rc != LG_OK) return rc;
+    }
+    hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, rt().stream, g, xhat, dw, db,
+                       partial, rt().gemm_tickets, rows, cols, chunk, dw_accumulate, db_accumulate);
+    LG_CHECK_LAUNCH();
+    return splits > 1 ? lg_free(partial) : LG_OK;
 }

@@ -174,7 +174,9 @@ int lg_malloc(void** ptr, size_t bytes) {
     LG_ARG(ptr != nullptr, "lg_malloc: ptr is NULL");
     Pool& P = pool();
     std::lock_guard<std::mutex> lock(P.mu);
-    size_t need = round_size(bytes);
+    // 16 bytes of slack behind every block: a float4 load that starts inside a tensor's last row may run up to 12 bytes
+    // past its end (GEMM operands whose contiguous extent is not a multiple of 4); the bytes are never used
+    size_t need = round_size(bytes + 16);
     void* p = nullptr;
     int tag = P.capture ? P.capture->id : 0;
     if (P.capture) p = take_from(P.capture->free_blocks, need);

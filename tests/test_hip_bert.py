@@ -124,3 +124,43 @@ def test_embedding_gather_and_scatter_add(hip):
         (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
         (ct[CpuTensor.from_numpy(ids, requires_grad=False)] * CpuTensor.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
         np.testing.assert_allclose(tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_parameter_gradients_accumulate_in_place(hip):
+    """second backward pass into existing gradient buffers (what a training step does after zero_grad): LayerNorm's
+    fused dw/db launch and the embedding scatter-add write into the parameters' buffers and must ADD - after an eager
+    zero_grad, after two passes without one, and on odd / split-over-workgroups shapes"""
+    import lightgrad_amd.nn as nn
+    rng = np.random.RandomState(21)
+    for rows, cols in [(1024, 128), (7, 5), (300, 257), (64, 1000)]:
+        x = rng.uniform(-2, 2, (rows, cols)).astype(np.float32)
+        w = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+        grads = {}
+        for cls in (CpuTensor, hip):
+            np.random.seed(3)
+            ln = nn.LayerNorm(cols)
+            ln.load_parameters({"weight": rng.uniform(0.5, 1.5, (cols,)).astype(np.float32) * 0 + 1.25, "bias": np.full((cols,), 0.5, np.float32)})
+            if cls is hip:
+                ln.map_parameters(lambda p: p.hip())
+            for _ in range(2):                                   # two passes, no zero_grad in between: grads add up
+                (ln(cls.from_numpy(x)) * cls.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+            twice = [ln.weight.grad.numpy().copy(), ln.bias.grad.numpy().copy()]
+            for p in ln.parameters():
+                p.zero_grad()
+            (ln(cls.from_numpy(x)) * cls.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+            grads[cls] = twice + [ln.weight.grad.numpy(), ln.bias.grad.numpy()]
+        scale = rows ** 0.5
+        for got, ref in zip(grads[hip], grads[CpuTensor]):
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(grads[hip][0], 2 * grads[hip][2], rtol=1e-5, atol=1e-5 * scale)
+    table = rng.uniform(-1, 1, (40, 8)).astype(np.float32)
+    ids = rng.randint(0, 40, (5, 6)).astype(np.int64)
+    w = rng.uniform(-1, 1, (5, 6, 8)).astype(np.float32)
+    tt, ct = hip.from_numpy(table), CpuTensor.from_numpy(table)
+    for cls, t in ((hip, tt), (CpuTensor, ct)):
+        for _ in range(2):
+            (t[cls.from_numpy(ids, requires_grad=False)] * cls.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_allclose(tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)
+    tt.zero_grad()
+    (tt[hip.from_numpy(ids, requires_grad=False)] * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_allclose(2 * tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)

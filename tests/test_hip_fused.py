@@ -155,3 +155,23 @@ def test_lazy_zero_grad_equals_fill_then_accumulate(hip):
         results[-1]["grad"] = model.shared.weight.grad.numpy()
     for name in results[0]:
         np.testing.assert_allclose(results[1][name], results[0][name], rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+def test_cross_entropy_vocabulary_sized_rows(hip):
+    """the one-workgroup-per-row kernel (cols >= 4096): BERT's (1024, 30522) logits, an odd width with -inf entries
+    (masked classes) and all label dtypes, against the oracle"""
+    rng = np.random.RandomState(6)
+    for (n, c), ldt in [((1024, 30522), np.int64), ((7, 4097), np.int32), ((3, 5000), np.int16)]:
+        logits = rng.uniform(-8, 8, (n, c)).astype(np.float32)
+        if c == 4097:
+            logits[:, 100:200] = -np.inf
+            logits[2, :] = -3.0                       # a constant row: uniform distribution
+        labels = rng.randint(0, 99, n).astype(ldt) if c == 4097 else rng.randint(0, c, n).astype(ldt)
+        with np.errstate(all="ignore"):
+            want_loss, want_grad = O.cross_entropy(logits, labels.astype(np.int64))
+        y = hip.from_numpy(logits)
+        loss = light.loss.cross_entropy(y, hip.from_numpy(labels, requires_grad=False))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), want_loss, rtol=2e-5)
+        np.testing.assert_allclose(y.grad.numpy(), want_grad, rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(y.grad.numpy().astype(np.float64).sum(-1), 0, atol=1e-6)

@@ -18,12 +18,21 @@ from ..tensor import AbstractTensor
 from . import lib as _l
 
 
+_strides_cache = {}
+
+
 def contiguous_strides(shape):
-    strides, acc = [], 1
-    for s in reversed(shape):
-        strides.append(acc)
-        acc *= s
-    return tuple(reversed(strides))
+    """row-major strides (in elements) of a dense tensor of this shape; cached - the same few shapes recur every step"""
+    st = _strides_cache.get(shape)
+    if st is None:
+        strides, acc = [], 1
+        for s in reversed(shape):
+            strides.append(acc)
+            acc *= s
+        st = tuple(reversed(strides))
+        if len(_strides_cache) < 4096:
+            _strides_cache[tuple(shape)] = st
+    return st
 
 
 class HipBuffer(object):
@@ -107,9 +116,9 @@ class HipTensor(AbstractTensor):
                  dtype: type = np.float32, requires_grad: bool = True):
         assert isinstance(buffer, HipBuffer)
         AbstractTensor.__init__(self, data=buffer, requires_grad=requires_grad)
-        self._dtype = np.dtype(dtype)
-        self._shape = tuple(int(s) for s in shape)
-        self._strides = contiguous_strides(self._shape) if strides is None else tuple(int(s) for s in strides)
+        self._dtype = dtype if dtype.__class__ is np.dtype else np.dtype(dtype)
+        self._shape = tuple(map(int, shape))
+        self._strides = contiguous_strides(self._shape) if strides is None else tuple(map(int, strides))
         self._offset = int(offset)
         assert len(self._shape) == len(self._strides), \
             "Shapes and strides do not align! (%s <-> %s)" % (self._shape, self._strides)

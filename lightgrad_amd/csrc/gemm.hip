@@ -3,10 +3,16 @@
 //
 // Structure (one workgroup = BM x BN tile of C, WM x WN waves, each wave a TM x TN grid of
 // 32x32 MFMA accumulators):
-//   global --float4--> registers --ds_write_b128--> LDS (double buffered) --> fragments --> MFMA
-//   * the next K-tile's global loads are issued BEFORE the MFMAs of the current tile and written
-//     to the other LDS buffer AFTER them: one barrier per K-tile, HBM/L2 latency hidden under
-//     BK/2 * TM * TN MFMAs (64 cycles each).
+//   global --buffer_load_dwordx4--> registers --ds_write_b128--> LDS (double buffered) --> fragments --> MFMA
+//   * global loads are inline-asm buffer loads with counted vmcnt waits (a ring of 1-2 K-tiles in flight): descriptor at
+//     the K-tile, loop-invariant 32-bit offsets, every predicate (row / column beyond the matrix, k beyond the slice)
+//     folded into an out-of-range offset that the hardware answers with 0 - no branches, no zero-fill in the K loop.
+//   * the next K-tile is requested BEFORE the MFMAs of the current tile and written to the other LDS buffer in the
+//     MIDDLE of them: one barrier per K-tile, L2 / HBM latency hidden under the MFMAs (64 cycles each).  Waves with a
+//     single accumulator also fetch the next half tile's LDS fragments under the current half's MFMAs.
+//   * too few tiles for 256 CUs: split-K INSIDE the launch (write-through partial tiles, per-tile ticket, the last
+//     workgroup to arrive folds them in slice order) - see the kernel; slice count from a fitted cost model.
+//   * epilogues: bias, accumulate (beta = 1), row sums of A as a virtual ones-column of B (dW and db in one launch).
 //   * operands are consumed in whatever layout the tensor has (A row- or column-major, B row- or
 //     column-major) - no transposition or padding copies.  A "K-contiguous" operand is staged as
 //     [row][BK+4] and a lane fetches FOUR k-values with one ds_read_b128; an "M/N-contiguous"

@@ -10,7 +10,8 @@
 //   red_cols : everything else - one thread per OUTPUT element walking the reduced index
 //              space (leading-axis sums such as the bias un-broadcast `sum((1024,512)->(1,512))`
 //              of func.py:50-56: lanes run along the contiguous kept axis, so loads coalesce);
-//              long reductions are split over blockIdx.y into partials.
+//              long reductions are split over blockIdx.y into partials that the last workgroup to
+//              arrive (per-column-block ticket) folds inside the same launch.
 // Semantics: opencl/ops.py:344-400 with cpu/ops.py:260-293 as numeric ground truth
 // (max/min exact incl. NaN propagation like np.max; sum is a tree sum in fp32).
 // The multi-pass LDS tree of opencl/kernels.py:344-501 is not reproduced.

@@ -41,6 +41,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kSmallTilePrefetch = LG_SMALL_PD;
 
+// n / d for n < 2^31 with a host-made multiplier: (n * m) >> s, m = floor(2^(31+l) / d) + 1, l = ceil(log2 d).  A lone
+// small workgroup cannot issue its first load before it knows its tile: five emulated integer divisions (~25
+// instructions each) at the top of the kernel are time it cannot hide.
+struct FastDiv {
+    uint32_t m, s;
+    __device__ __forceinline__ int div(int n) const { return int((uint64_t(uint32_t(n)) * m) >> s); }
+};
+static FastDiv make_fastdiv(int64_t d) {
+    if (d < 1) d = 1;
+    uint32_t l = 0;
+    while ((int64_t(1) << l) < d) ++l;
+    FastDiv f;
+    f.m = uint32_t((uint64_t(1) << (31 + l)) / uint64_t(d) + 1);
+    f.s = 31 + l;
+    return f;
+}
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -66,6 +83,7 @@ struct GemmArgs {
     // of C against a VIRTUAL column of ones appended to op(B) - the tiling, split-K and fold treat it like any column
     float*  rowsum;         // [M] or NULL
     int     rowsum_accumulate;
+    FastDiv div_per_batch, div_slices, div_gspan, div_group, div_last_group, div_batch_inner;
     int     k_tail;         // K % 4 != 0: K-contiguous float4s of the last tile carry elements beyond K, zeroed before LDS
 };
 
@@ -106,19 +124,22 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     // tile coordinates
     const int id = xcd_remap(blockIdx.x, g.nwg);
     const int per_batch = g.tiles_m * g.tiles_n;
-    const int bs = id / per_batch;                 // (batch, k-slice) pair
-    const int batch = bs / g.k_slices, slice = bs - batch * g.k_slices;
+    const int bs = g.div_per_batch.div(id);        // (batch, k-slice) pair
+    const int batch = g.div_slices.div(bs), slice = bs - batch * g.k_slices;
     const int t = id - bs * per_batch;
     // grouped order: consecutive ids walk GROUP_M tile rows before moving to the next tile column, so the
     // ~64 workgroups resident on one XCD at a time cover a near-square patch of C and share both their
     // A row-panels and their B column-panels in that XCD's 4 MiB L2
     const int GROUP_M = g.group_m;
     const int gspan = GROUP_M * g.tiles_n;
-    const int first_m = (t / gspan) * GROUP_M;
-    const int gsize = (g.tiles_m - first_m) < GROUP_M ? (g.tiles_m - first_m) : GROUP_M;
-    const int tm = first_m + (t % gspan) % gsize, tn = (t % gspan) / gsize;
+    const int group = g.div_gspan.div(t);
+    const int first_m = group * GROUP_M, in_group = t - group * gspan;
+    const bool last_group = g.tiles_m - first_m < GROUP_M;
+    const int gsize = last_group ? g.tiles_m - first_m : GROUP_M;
+    const int tn = last_group ? g.div_last_group.div(in_group) : g.div_group.div(in_group);
+    const int tm = first_m + (in_group - tn * gsize);
     const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-    const int b_outer = batch / g.batch_inner, b_inner = batch - b_outer * g.batch_inner;
+    const int b_outer = g.div_batch_inner.div(batch), b_inner = batch - b_outer * g.batch_inner;
     const float* __restrict__ A = g.A + int64_t(b_outer) * g.sA + int64_t(b_inner) * g.sA2;
     const float* __restrict__ B = g.B + int64_t(b_outer) * g.sB + int64_t(b_inner) * g.sB2;
     float* __restrict__ C = g.C + int64_t(b_outer) * g.sC + int64_t(b_inner) * g.sC2;
@@ -157,8 +178,9 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         if constexpr (VA) { if constexpr (AKC) { row = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BM / 4); row = (f % (BM / 4)) * 4; } }
         else              { if constexpr (AKC) { row = f / BK; kk = f % BK; } else { kk = f / BM; row = f % BM; } }
         kcA[i] = kk;
-        const int64_t bytes = AKC ? (int64_t(row) * g.lda + kk) * 4 : (int64_t(kk) * g.lda + row) * 4;
-        offA[i] = (m0 + row < g.M) ? unsigned(bytes) : OOB;
+        // 32-bit on purpose: the host guarantees that a tile's farthest byte offset is below 2^31
+        const unsigned bytes = AKC ? (unsigned(row) * unsigned(g.lda) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.lda) + unsigned(row)) * 4u;
+        offA[i] = (m0 + row < g.M) ? bytes : OOB;
     }
 #pragma unroll
     for (int i = 0; i < B_CHUNKS; ++i) {
@@ -167,8 +189,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         if constexpr (VB) { if constexpr (BKC) { col = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BN / 4); col = (f % (BN / 4)) * 4; } }
         else              { if constexpr (BKC) { col = f / BK; kk = f % BK; } else { kk = f / BN; col = f % BN; } }
         kcB[i] = kk;
-        const int64_t bytes = BKC ? (int64_t(col) * g.ldb + kk) * 4 : (int64_t(kk) * g.ldb + col) * 4;
-        offB[i] = (n0 + col < g.N) ? unsigned(bytes) : OOB;
+        const unsigned bytes = BKC ? (unsigned(col) * unsigned(g.ldb) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.ldb) + unsigned(col)) * 4u;
+        offB[i] = (n0 + col < g.N) ? bytes : OOB;
         if (has_virtual && n0 + col == g.N) virt_mask |= 1u << i;
     }
     const float* const Atile0 = AKC ? A + m0 * g.lda : A + m0;      // + k0 (AKC) / + k0 * lda per K-tile
@@ -574,6 +596,12 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
     g.k_slices = int(slices);
     g.nwg = int(tiles * slices);
+    g.div_per_batch = make_fastdiv(int64_t(g.tiles_m) * g.tiles_n);
+    g.div_slices = make_fastdiv(slices);
+    g.div_gspan = make_fastdiv(int64_t(g.group_m) * g.tiles_n);
+    g.div_group = make_fastdiv(g.group_m);
+    g.div_last_group = make_fastdiv(g.tiles_m % g.group_m ? g.tiles_m % g.group_m : g.group_m);
+    g.div_batch_inner = make_fastdiv(g.batch_inner);
     g.W = nullptr;
     g.tickets = rt().gemm_tickets;
     if (slices > 1 && tiles > rt().n_gemm_tickets) {       // more tiles than tickets: plenty of workgroups anyway
@@ -581,6 +609,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         g.k_per_slice = (g.K + BK - 1) / BK * BK;
         g.k_slices = 1;
         g.nwg = int(tiles);
+        g.div_slices = make_fastdiv(1);
     }
     if (slices > 1) {
         int rc = lg_malloc(reinterpret_cast<void**>(&g.W), size_t(tiles * slices) * BM * BN * sizeof(float));

@@ -84,9 +84,15 @@ namespace lg {
 __global__ void __launch_bounds__(256) adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                 float* __restrict__ v, int64_t n, AdamScalars c, const int64_t* __restrict__ step,
                                                 int64_t t_mul, int64_t t_add, double b1, double b2) {
-    const double t = double(step[0] * t_mul + t_add);
-    c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
-    c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
+    __shared__ float inv_bias[2];
+    if (threadIdx.x == 0) {          // the double-precision powers once per workgroup, not once per thread
+        const double t = double(step[0] * t_mul + t_add);
+        inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
+        inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
+    }
+    __syncthreads();
+    c.inv_bias1 = inv_bias[0];
+    c.inv_bias2 = inv_bias[1];
     int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(p[i], g[i], m[i], v[i], c);
 }
@@ -133,16 +139,46 @@ struct AdamSegments {
 
 __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, AdamSegments seg, AdamScalars c,
-                                                      int64_t* __restrict__ step, double b1, double b2, int advance) {
+                                                      int64_t* __restrict__ step, double b1, double b2, int advance, int base_aligned) {
+    __shared__ float inv_bias[2];
     const int j = blockIdx.y;
     const int64_t begin = seg.offsets[j], n = seg.offsets[j + 1] - begin;
-    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const double t = double(step[0] * seg.nseg + j + 1);
-        c.inv_bias1 = float(1.0 / (1.0 - pow(b1, t)));
-        c.inv_bias2 = float(1.0 / (1.0 - pow(b2, t)));
-        const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-        for (; i < n; i += stride) adam_elem(p[begin + i], g[begin + i], m[begin + i], v[begin + i], c);
+    // four elements per thread where the segment allows 16-byte accesses (vec == 1), else one
+    const int vec = (base_aligned && (begin & 3) == 0) ? 1 : 0;
+    const int64_t first = (int64_t(blockIdx.x) * blockDim.x) * (vec ? 4 : 1);
+    if (first < n) {                                   // workgroup-uniform
+        if (threadIdx.x == 0) {
+            // the two double-precision powers once per workgroup, not once per thread (they were most of the kernel)
+            const double t = double(step[0] * seg.nseg + j + 1);
+            inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
+            inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
+        }
+        __syncthreads();
+        c.inv_bias1 = inv_bias[0];
+        c.inv_bias2 = inv_bias[1];
+        float* P = p + begin;
+        const float* G = g + begin;
+        float* M = m + begin;
+        float* V = v + begin;
+        if (vec) {
+            const int64_t nvec = n / 4, stride = int64_t(gridDim.x) * blockDim.x;
+            for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+                float4 pp = reinterpret_cast<float4*>(P)[i], gg = reinterpret_cast<const float4*>(G)[i];
+                float4 mm = reinterpret_cast<float4*>(M)[i], vv = reinterpret_cast<float4*>(V)[i];
+                adam_elem(pp.x, gg.x, mm.x, vv.x, c);
+                adam_elem(pp.y, gg.y, mm.y, vv.y, c);
+                adam_elem(pp.z, gg.z, mm.z, vv.z, c);
+                adam_elem(pp.w, gg.w, mm.w, vv.w, c);
+                reinterpret_cast<float4*>(P)[i] = pp;
+                reinterpret_cast<float4*>(M)[i] = mm;
+                reinterpret_cast<float4*>(V)[i] = vv;
+            }
+            if (blockIdx.x == 0)
+                for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) adam_elem(P[i], G[i], M[i], V[i], c);
+        } else {
+            const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+            for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
+        }
     }
     if (advance) {
         // the LAST workgroup to finish advances the step number (step[1] is an arrival ticket, zero between launches):
@@ -182,7 +218,10 @@ extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* 
     c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
     c.eps = float(eps); c.inv_bias1 = 0.f; c.inv_bias2 = 0.f; c.gscale = float(gscale); c.belief = belief;
     c.scale_grad = gscale != 1.0;
-    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid(longest), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2, advance);
+    // sized for four elements per thread (segments that do not start on a 16-byte boundary loop: grid-stride)
+    const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
+    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid((longest + 3) / 4), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
+                       advance, base_aligned);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -131,7 +131,12 @@ class reshape(Function):
         if m != n:
             raise ValueError("cannot reshape tensor of size %d into shape %s" % (n, shape))
         src = a.contiguous()
-        return HipTensor(src.data, shape, None, src._offset, a._dtype)
+        out = HipTensor(src.data, shape, None, src._offset, a._dtype)
+        if src is a and a.ctx is None and a.requires_grad:
+            # a dense reshape of a LEAF (the `x.reshape(-1, 784)` of an MLP's input): gradients for the view may be added
+            # straight into the leaf's gradient buffer, see HipTensor._grad_accumulator
+            out._view_of_leaf = a
+        return out
 
     def backward(ctx, out_grad):
         shape, = ctx.get_saved_tensors()

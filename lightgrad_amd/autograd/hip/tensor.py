@@ -195,6 +195,26 @@ class HipTensor(AbstractTensor):
             _l.check(_l.lib().lg_memcpy_h2d(t.ptr, a.ctypes.data, a.nbytes))
         return t
 
+    # set by `reshape` on a dense view of a leaf tensor: the leaf whose gradient buffer this view's gradient lands in
+    _view_of_leaf = None
+
+    def _grad_accumulator(self):
+        """AbstractTensor's rule (a leaf that already owns a dense gradient), extended to dense reshape views of such a
+        leaf: `leaf.grad += g.reshape(leaf.shape)` - what reshape.backward + add_grad would do with the view's gradient -
+        is the same as adding g into a reshaped view of leaf.grad, so a backward kernel may accumulate there directly
+        (and report None for the view: the reshape node then has nothing left to propagate)."""
+        acc = AbstractTensor._grad_accumulator(self)
+        if acc is None and self._view_of_leaf is not None and self._grad is None:
+            base = AbstractTensor._grad_accumulator(self._view_of_leaf)
+            if base is not None and base.is_contiguous() and base.numel() == self.numel():
+                return HipTensor(base.data, self._shape, None, base._offset, base._dtype, requires_grad=False)
+        return acc
+
+    def _consume_zero_pending(self) -> bool:
+        if self._view_of_leaf is not None and self._grad is None:
+            return self._view_of_leaf._consume_zero_pending()
+        return AbstractTensor._consume_zero_pending(self)
+
     _unit_seeds = {}          # shape -> constant tensor of ones used as the backward seed of item tensors
 
     def _seed_gradient(self):

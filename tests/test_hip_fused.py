@@ -175,3 +175,30 @@ def test_cross_entropy_vocabulary_sized_rows(hip):
         np.testing.assert_allclose(loss.item(), want_loss, rtol=2e-5)
         np.testing.assert_allclose(y.grad.numpy(), want_grad, rtol=2e-5, atol=1e-9)
         np.testing.assert_allclose(y.grad.numpy().astype(np.float64).sum(-1), 0, atol=1e-6)
+
+
+def test_gradient_of_a_reshaped_leaf_lands_in_the_leaf(hip):
+    """`x.reshape(-1, d)` of a leaf that already owns a gradient (a static input re-used across steps): the first
+    Linear adds dx straight into x.grad through the view; same values as reshape.backward + `x.grad += ...`, also when
+    the view has a second consumer and after a zero_grad"""
+    rng = np.random.RandomState(14)
+    xn, tn = rng.uniform(-1, 1, (6, 2, 5)).astype(np.float32), rng.uniform(0, 1, (12, 3)).astype(np.float32)
+    grads = {}
+    for cls in (CpuTensor, hip):
+        np.random.seed(5)
+        lin = light.nn.Linear(5, 3)
+        if cls is hip:
+            lin.map_parameters(lambda p: p.hip())
+        x, t = cls.from_numpy(xn), cls.from_numpy(tn, requires_grad=False)
+        out = []
+        for step in range(3):
+            flat = x.reshape(-1, 5)
+            loss = light.loss.mse(lin(flat), t) + (flat * flat).sum() * 0.01        # the view has two consumers
+            loss.backward()
+            out.append(x.grad.numpy().copy())
+            if step == 1:
+                x.zero_grad()
+        grads[cls] = out
+    for got, ref in zip(grads[hip], grads[CpuTensor]):
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert np.abs(grads[hip][1]).sum() > 1.5 * np.abs(grads[hip][0]).sum()          # second pass accumulated

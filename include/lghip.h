@@ -209,6 +209,18 @@ int lg_gemm_bias_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, const float* bias);
 
+/* One matrix product with every epilogue / prologue the tape can fold into it (any of them may be off):
+ *   bias [N]            added to every row (nn.py:96)                                      - excludes accumulate, rowsum
+ *   rowsum [M]          (+)= row sums of op(A), see lg_gemm_rowsum_f32
+ *   relu_a / relu_b     op(A) / op(B) pass through np.maximum(., 0) (cpu/ops.py:226) on their way to LDS: the consumer of
+ *                       a relu reads the PRE-activation, the relu kernel and its output tensor are never made
+ * (The (t >= 0) factor of relu's backward is NOT folded into the input-gradient GEMM: the relu output's own `.grad` -
+ * readable on every tensor of the tape, tensor.py:40-42 - would then hold the masked values.) */
+int lg_gemm_fused_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                      const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                      int accumulate, const float* bias, float* rowsum, int rowsum_accumulate,
+                      int relu_a, int relu_b);
+
 /* lg_gemm_f32 over a TWO-level batch: matrix (o, i) of operand X starts at X + o*strideX_outer + i*strideX_inner.
  * One launch for attention-shaped products whose (batch, head) dims do not collapse into one stride after the head
  * split `reshape(b, s, h, d).transpose(0, 2, 1, 3)` (examples/bert.py:70-95; the reference's kernel is launched per

@@ -417,6 +417,37 @@ def _gemm_rowsum(a, b, accumulate_into=None, overwrite=False, rowsum_into=None, 
     return out, rowsum
 
 
+def _gemm_fused(a, b, bias=None, accumulate_into=None, overwrite=False, rowsum_into=None, rowsum_overwrite=False,
+                want_rowsum=False, relu_a=False, relu_b=False):
+    """2-D a @ b through lg_gemm_fused_f32: optional bias, accumulation into an existing buffer, row sums of a, relu on
+    either operand on the fly.  Returns (out, rowsum|None)."""
+    _require_f32(a, b)
+    (M, K), (K2, N) = a._shape, b._shape
+    assert K == K2 and M > 0 and N > 0
+    ma, mb = _as_mat(a), _as_mat(b)
+    out = accumulate_into if accumulate_into is not None else HipTensor.empty((M, N))
+    assert out._shape == (M, N) and out.is_contiguous()
+    rowsum = None
+    if want_rowsum or rowsum_into is not None:
+        rowsum = rowsum_into if rowsum_into is not None else HipTensor.empty((M,))
+        assert rowsum._shape == (M,) and rowsum.is_contiguous()
+    if bias is not None:
+        assert bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32 and accumulate_into is None and rowsum is None
+    _l.check(_l.lib().lg_gemm_fused_f32(
+        1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K, ma.t.ptr, ma.ld, mb.t.ptr, mb.ld, out.ptr, N,
+        1 if (accumulate_into is not None and not overwrite) else 0, bias.ptr if bias is not None else None,
+        rowsum.ptr if rowsum is not None else None, 1 if (rowsum_into is not None and not rowsum_overwrite) else 0,
+        1 if relu_a else 0, 1 if relu_b else 0))
+    return out, rowsum
+
+
+def _lazy_relu_input(x):
+    """the pre-activation t if x is a still-lazy relu(t) that a 2-D GEMM can read in its place, else None"""
+    if x._data is None and x._lazy_source is not None and x._lazy_source[0] == "relu" and len(x._shape) == 2:
+        return x._lazy_source[1]
+    return None
+
+
 def _is_colmajor(t):
     return len(t._shape) >= 2 and t._strides[-2] == 1 and t._shape[-1] > 1 and t._strides[-1] != 1
 
@@ -546,8 +577,24 @@ cos = HipTensor.register_op("cos", _unary_op("cos", _l.EW_COS, _l.EW_COS_BWD, Fa
 sigmoid = HipTensor.register_op("sigmoid", _unary_op("sigmoid", _l.EW_SIGMOID, _l.EW_SIGMOID_BWD, True, "cpu/ops.py:199-208"),
                                 overwrite=True)
 tanh = HipTensor.register_op("tanh", _unary_op("tanh", _l.EW_TANH, _l.EW_TANH_BWD, True, "cpu/ops.py:210-219"), overwrite=True)
-relu = HipTensor.register_op("relu", _unary_op("relu", _l.EW_RELU, _l.EW_RELU_BWD, False,
-                                               "gradient passes at exactly 0: g * (t >= 0) (cpu/ops.py:221-229)"))
+@HipTensor.register_op()
+class relu(Function):
+    """ np.maximum(t, 0); gradient passes at exactly 0: g * (t >= 0) (cpu/ops.py:221-229).
+    The result is LAZY for dense inputs (HipTensor._lazy_source): `linear` folds the relu into its GEMMs - as forward
+    operand and as weight-gradient operand - so that in `Linear -> relu -> Linear` the relu kernel never runs and its
+    output is never written; every other consumer makes the tensor real by asking for its data. """
+    def forward(ctx, t):
+        _require_f32(t)
+        ctx.save_for_backward(t)
+        if t.is_contiguous() and t.numel() > 0:
+            out = HipTensor(None, t._shape, None, 0, t._dtype)
+            out._lazy_source = ("relu", t)
+            return out
+        return _unary(_l.EW_RELU, t)
+
+    def backward(ctx, out_grad):
+        t, = ctx.get_saved_tensors()
+        return _binary(_l.EW_RELU_BWD, t, out_grad)
 
 
 """ Selectors """
@@ -795,6 +842,10 @@ class linear(Function):
     dot.backward + transpose.backward + the un-broadcast of func.py:50-56 produce. """
     def forward(ctx, x, weight, bias=None):
         ctx.save_for_backward(x, weight, bias is not None)
+        pre = _lazy_relu_input(x)
+        if pre is not None and x._shape[0] > 0:
+            # x = relu(pre) that nobody has looked at yet: the GEMM reads pre and applies the relu while staging it
+            return _gemm_fused(pre, _swap_last(weight), bias=bias, relu_a=True)[0]
         return _gemm(x, _swap_last(weight), bias=bias)
 
     def backward(ctx, out_grad):
@@ -802,6 +853,9 @@ class linear(Function):
         bias = ctx._parents[2] if has_bias else None
         out_f = weight._shape[0]
         g2 = out_grad.reshape(-1, out_f)
+        pre = _lazy_relu_input(x) if g2._shape[0] > 0 else None
+        if pre is not None:
+            return linear._backward_through_lazy_relu(x, pre, weight, bias, g2)
         x2 = x.reshape(-1, x._shape[-1])
         # leaf operands that already own a gradient buffer (parameters after zero_grad, a re-used input) get their
         # gradient ADDED in place by the producing kernel (GEMM with beta = 1 / reduction with accumulate) and None
@@ -840,6 +894,41 @@ class linear(Function):
             else:
                 db = _reduce(_l.RED_SUM, g2, (0,), False)
         return dx, dw, db
+
+
+def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
+    """linear.backward when the saved input x = relu(pre) was never made: dW (+ db) read pre with the relu applied on
+    the fly.  dx is the plain g @ W: the relu output's own gradient stays what the tape says it is (its (pre >= 0)
+    factor is relu.backward's job).  Same values as with a materialised x."""
+    dw = dx = db = None
+    want_db = bias is not None and bias.requires_grad
+    if weight.requires_grad:
+        acc_w = weight._grad_accumulator()
+        acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+        acc_b = bias._grad_accumulator() if want_db else None
+        acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+        out_w, out_b = _gemm_fused(_swap_last(g2), pre, relu_b=True, accumulate_into=acc_w,
+                                   overwrite=acc_w is not None and weight._consume_zero_pending(),
+                                   want_rowsum=want_db, rowsum_into=acc_b,
+                                   rowsum_overwrite=acc_b is not None and bias._consume_zero_pending())
+        dw = out_w if acc_w is None else None
+        if want_db:
+            db = out_b if acc_b is None else None
+            want_db = False
+    if x.requires_grad:
+        dx = _gemm(g2, weight)
+    if bias is None:
+        return dx, dw
+    if want_db:
+        acc = bias._grad_accumulator()
+        if acc is not None and acc.is_contiguous():
+            _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())
+        else:
+            db = _reduce(_l.RED_SUM, g2, (0,), False)
+    return dx, dw, db
+
+
+linear._backward_through_lazy_relu = staticmethod(_linear_backward_through_lazy_relu)
 
 
 gelu = HipTensor.register_op("gelu", _unary_op("gelu", _l.EW_GELU, _l.EW_GELU_BWD, False,

@@ -114,7 +114,7 @@ class HipTensor(AbstractTensor):
 
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):
-        assert isinstance(buffer, HipBuffer)
+        assert isinstance(buffer, HipBuffer) or buffer is None        # None: a lazy tensor, see _lazy_source
         AbstractTensor.__init__(self, data=buffer, requires_grad=requires_grad)
         self._dtype = dtype if dtype.__class__ is np.dtype else np.dtype(dtype)
         self._shape = tuple(map(int, shape))
@@ -140,10 +140,33 @@ class HipTensor(AbstractTensor):
     def offset(self) -> int:
         return self._offset
 
+    # A LAZY tensor has no buffer yet: `_lazy_source` = (kind, input tensor) says how to make it ("relu" only).  It is
+    # created by relu.forward; a consumer that can fold the relu into its own kernel (linear) reads the input instead and
+    # the relu never runs.  Anything else that asks for `data` / `ptr` runs it first - so a lazy tensor behaves like
+    # any other everywhere, it just costs nothing until someone looks.
+    _lazy_source = None
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._materialize()
+        return self._data
+
+    def is_lazy(self) -> bool:
+        return self._data is None
+
+    def _materialize(self) -> None:
+        kind, src = self._lazy_source
+        assert kind == "relu"
+        from . import ops as _ops
+        out = HipTensor.empty(self._shape, requires_grad=False)
+        _ops._ew(_l.EW_RELU, self._shape, [src], out=out)
+        self._data, self._offset, self._lazy_source = out._data, out._offset, None
+
     @property
     def ptr(self) -> int:
         """device address of element [0, ..., 0]"""
-        return self._data.ptr + self._offset * self._dtype.itemsize
+        return self.data.ptr + self._offset * self._dtype.itemsize
 
     def numel(self) -> int:
         n = 1

@@ -85,6 +85,9 @@ struct GemmArgs {
     int     rowsum_accumulate;
     FastDiv div_per_batch, div_slices, div_gspan, div_group, div_last_group, div_batch_inner;
     int     k_tail;         // K % 4 != 0: K-contiguous float4s of the last tile carry elements beyond K, zeroed before LDS
+    // relu folded into its consumers (the tape's relu stays lazy, autograd/hip/ops.py): op(A) / op(B) are passed through
+    // np.maximum(., 0) on their way to LDS
+    int     relu_a, relu_b;
 };
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
@@ -267,6 +270,18 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                         if (kcB[i] + e >= krem_ring[slot]) rb_ring[slot][i][e] = 0.f;
             }
         }
+        if constexpr (kCanSplitK<BM, BN>) if (g.relu_a) {
+            asm volatile("; relu(A) on the way to LDS" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < A_CHUNKS; ++i) {
+                if constexpr (VA) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float x = ra_ring[slot][i][e]; ra_ring[slot][i][e] = (x != x) ? x : (x > 0.0f ? x : 0.0f); }
+                } else {
+                    const float x = ra_ring[slot][i]; ra_ring[slot][i] = (x != x) ? x : (x > 0.0f ? x : 0.0f);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int f = tid + i * NT;
@@ -276,6 +291,18 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             } else {
                 if constexpr (AKC) a[(f / BK) * A_PITCH + (f % BK)] = ra_ring[slot][i];
                 else               a[(f / BM) * A_PITCH + (f % BM)] = ra_ring[slot][i];
+            }
+        }
+        if constexpr (kCanSplitK<BM, BN>) if (g.relu_b) {
+            asm volatile("; relu(B) on the way to LDS" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < B_CHUNKS; ++i) {
+                if constexpr (VB) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float x = rb_ring[slot][i][e]; rb_ring[slot][i][e] = (x != x) ? x : (x > 0.0f ? x : 0.0f); }
+                } else {
+                    const float x = rb_ring[slot][i]; rb_ring[slot][i] = (x != x) ? x : (x > 0.0f ? x : 0.0f);
+                }
             }
         }
         if constexpr (kCanSplitK<BM, BN>) if (has_virtual) {
@@ -634,7 +661,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      const float* B, int64_t ldb, int64_t strideB,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0,
-                     int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0) {
+                     int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0,
+                     int relu_a = 0, int relu_b = 0) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -679,6 +707,9 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.rowsum = rowsum;
     g.rowsum_accumulate = rowsum_accumulate;
     g.k_tail = (K % 4 != 0) ? 1 : 0;
+    g.relu_a = relu_a; g.relu_b = relu_b;
+    const bool fused_extras = rowsum != nullptr || relu_a || relu_b;     // not compiled into the 256x256 tile
+    LG_ARG(!(relu_a || relu_b) || batch == 1, "lg_gemm_fused_f32: one matrix product");
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
     if (g.group_m < 1) g.group_m = 1;
@@ -717,12 +748,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const int64_t per_cu = (nblocks(bm, bn) + cus - 1) / cus;
                 return double(per_cu) * double(bm * bn) / eff;
             };
-            const double c256 = rowsum ? 1e300 : cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
+            const double c256 = fused_extras ? 1e300 : cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
             tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
         }
         switch (tile) {
             case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
-            case 2:  if (!rowsum) { rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break; }   // else: 128
+            case 2:  if (!fused_extras) { rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break; }   // else: 128
             case 9:  rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
             default: rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
         }
@@ -764,4 +795,14 @@ extern "C" int lg_gemm_batched2_f32(int transA, int transB, int64_t M, int64_t N
     if (batch_outer == 0 || batch_inner == 0) return LG_OK;
     return gemm_impl(transA, transB, M, N, K, A, lda, strideA_outer, B, ldb, strideB_outer, C, ldc, strideC_outer,
                      batch_outer * batch_inner, accumulate, nullptr, nullptr, 0, batch_inner, strideA_inner, strideB_inner, strideC_inner);
+}
+
+extern "C" int lg_gemm_fused_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                 const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                 int accumulate, const float* bias, float* rowsum, int rowsum_accumulate,
+                                 int relu_a, int relu_b) {
+    LG_ARG(!(bias && rowsum), "lg_gemm_fused_f32: bias and rowsum exclude each other");
+    LG_ARG(!(bias && accumulate), "lg_gemm_fused_f32: bias and accumulate exclude each other");
+    return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, accumulate, bias, rowsum, rowsum_accumulate,
+                     1, 0, 0, 0, relu_a, relu_b);
 }

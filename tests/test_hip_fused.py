@@ -202,3 +202,55 @@ def test_gradient_of_a_reshaped_leaf_lands_in_the_leaf(hip):
     for got, ref in zip(grads[hip], grads[CpuTensor]):
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
     assert np.abs(grads[hip][1]).sum() > 1.5 * np.abs(grads[hip][0]).sum()          # second pass accumulated
+
+
+def test_lazy_relu_is_folded_into_linear_and_invisible_elsewhere(hip):
+    """relu of a dense tensor is lazy: Linear reads the pre-activation (forward operand and weight-gradient operand)
+    and the relu kernel never runs; every other use makes it real.  Values, ALL gradients (the relu output's own
+    included) and NaN / zero handling equal the CPU backend's."""
+    rng = np.random.RandomState(17)
+    xn = rng.uniform(-1, 1, (33, 20)).astype(np.float32)
+    xn[0, 0], xn[1, 1] = 0.0, -0.0
+    tn = rng.uniform(0, 1, (33, 7)).astype(np.float32)
+    res = {}
+    for cls in (CpuTensor, hip):
+        np.random.seed(9)
+        l1, l2 = light.nn.Linear(20, 16), light.nn.Linear(16, 7)
+        if cls is hip:
+            l1.map_parameters(lambda p: p.hip())
+            l2.map_parameters(lambda p: p.hip())
+        x = cls.from_numpy(xn)
+        pre = l1(x)
+        h = pre.relu()
+        if cls is hip:
+            assert h.is_lazy()
+        y = l2(h)
+        if cls is hip:
+            assert h.is_lazy(), "Linear must not have materialised its relu input"
+        loss = light.loss.mse(y, cls.from_numpy(tn, requires_grad=False))
+        loss.backward()
+        if cls is hip:
+            assert h.is_lazy()
+        res[cls] = [y.numpy(), h.grad.numpy(), pre.grad.numpy(), x.grad.numpy()] + [p.grad.numpy() for p in list(l1.parameters()) + list(l2.parameters())]
+        res[cls].append(h.numpy())                                  # looking at it makes it real
+        if cls is hip:
+            assert not h.is_lazy()
+    for got, ref in zip(res[hip], res[CpuTensor]):
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    # direct uses of a lazy relu: elementwise, reduction, view, numpy, second Linear after materialisation, NaN
+    a = rng.uniform(-1, 1, (9, 12)).astype(np.float32)
+    a[3, 3] = np.nan
+    ta = hip.from_numpy(a)
+    with np.errstate(all="ignore"):
+        want = np.maximum(a, 0)
+        np.testing.assert_array_equal(ta.relu().numpy(), want)
+        np.testing.assert_array_equal((ta.relu() + 1.0).numpy(), want + 1.0)
+        np.testing.assert_array_equal(ta.relu().transpose(1, 0).contiguous().numpy(), want.T)
+        np.testing.assert_array_equal(ta.relu().reshape(3, 36).numpy(), want.reshape(3, 36))
+        w = rng.uniform(-1, 1, (5, 12)).astype(np.float32)
+        got = ta.relu().linear(hip.from_numpy(w)).numpy()
+        ref = want.astype(np.float64) @ w.T
+        np.testing.assert_allclose(got[np.arange(9) != 3], ref[np.arange(9) != 3], rtol=1e-5, atol=1e-5)
+        assert np.isnan(got[3]).all()
+    r = hip.from_numpy(a[:2]).relu()
+    np.testing.assert_allclose(r.sum().item(), np.maximum(a[:2], 0).sum(), rtol=1e-5)

@@ -13,6 +13,7 @@ There is no CPU fallback anywhere in this class: without liblghip.so and a GPU
 every constructor raises `HipError`.
 """
 import ctypes
+import os
 import numpy as np
 from ..tensor import AbstractTensor
 from . import lib as _l
@@ -363,8 +364,8 @@ class HipTensor(AbstractTensor):
         assert offsets[-1] == self.numel()
         _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
                                                 lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 0))
-        # advance = 0: the ticket form (last workgroup increments the counter) costs one contended atomic per workgroup,
-        # measured +68 us on the 6272-workgroup MLP update; a separate 1-thread launch (lg_counter_add_i64) costs ~3 us
+        # advance = 0: the ticket form (the last working workgroup increments the counter) costs one contended atomic per
+        # working workgroup - measured 2 % slower per MLP step (~400 tickets) than the separate 1-thread launch below
         self._advance_step_counter(step_counter)
 
     @staticmethod

@@ -180,14 +180,14 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
             for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
         }
     }
-    if (advance) {
-        // the LAST workgroup to finish advances the step number (step[1] is an arrival ticket, zero between launches):
-        // every workgroup has read step[0] before it draws its ticket, so the write cannot race with a read
+    if (advance > 0 && first < n) {
+        // the LAST working workgroup to finish advances the step number (step[1] is an arrival ticket, zero between
+        // launches; `advance` = number of workgroups that have work): every workgroup has read step[0] before it draws
+        // its ticket, so the write cannot race with a read
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
             const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ULL);
-            if (ticket == total - 1) {
+            if (ticket == (unsigned long long)advance - 1) {
                 step[1] = 0;
                 step[0] = step[0] + 1;
             }
@@ -220,7 +220,18 @@ extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* 
     c.scale_grad = gscale != 1.0;
     // sized for four elements per thread (segments that do not start on a 16-byte boundary loop: grid-stride)
     const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
-    hipLaunchKernelGGL(adam_multi_dev, dim3(stream_grid((longest + 3) / 4), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
+    const int64_t grid_x = stream_grid((longest + 3) / 4);
+    if (advance) {                    // number of workgroups with work: they take the arrival tickets
+        int64_t active = 0;
+        for (int j = 0; j < nseg; ++j) {
+            const int64_t n = offsets[j + 1] - offsets[j];
+            const int64_t per_wg = 256 * ((base_aligned && (offsets[j] & 3) == 0) ? 4 : 1);
+            const int64_t wgs = (n + per_wg - 1) / per_wg;
+            active += wgs < grid_x ? wgs : grid_x;
+        }
+        advance = int(active);
+    }
+    hipLaunchKernelGGL(adam_multi_dev, dim3(unsigned(grid_x), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
                        advance, base_aligned);
     LG_CHECK_LAUNCH();
     return LG_OK;

@@ -367,7 +367,23 @@ def main():
         t0 = time.perf_counter()
         O.matmul_fwd_bwd(an, bn)
         cpu_mm = time.perf_counter() - t0
+        # the same step on ONE BLAS thread (SURVEY.md 8d asks for both): a short sample
+        one_thread = None
+        try:
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1):
+                t0 = time.perf_counter()
+                n1 = 0
+                while time.perf_counter() - t0 < 4.0 and n1 < 200:
+                    _, grads, _ = O.mlp_loss_and_grads(w, xc, tc)
+                    for name in O.PARAM_ORDER:
+                        w[name] += o_opt.delta(name, grads[name])
+                    n1 += 1
+                one_thread = round(n1 / (time.perf_counter() - t0), 2)
+        except Exception:            # threadpoolctl missing or BLAS not controllable: report the all-threads number only
+            one_thread = None
         cpu_baseline = {"value": round(cpu_steps, 2), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                        "value_one_blas_thread": one_thread,
                         "sample": "%d MLP training steps (same shapes, numpy oracle, BLAS default threads) in ~10 s; "
                                   "matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s" % (n_cpu, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
                         "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3), "numpy": np.__version__}

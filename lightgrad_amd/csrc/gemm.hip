@@ -729,7 +729,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     auto nblocks = [&](int64_t bm, int64_t bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     LG_ARG(nblocks(32, 32) < (int64_t(1) << 30), "lg_gemm_f32: problem too large for one launch");
     // Tile choice.  Skinny outputs take the 64x32 / 32x64 tiles.  Otherwise three tiles compete:
-    //   256x256 (16 waves, 1 WG/CU)  132-141 TFLOP/s at 4096^3   128x128 (4 waves)  ~124   64x64 (4 waves, + split-K)  ~107 at 3072^3
+    //   256x256 (16 waves, 1 WG/CU)  140-143 TFLOP/s at 4096^3   128x128 (4 waves)  ~132   64x64 (4 waves, + split-K)  138-139 at
+    //   4096^3, 134 at 3072^3, 126 at 2048^3 (efficiencies refitted after the buffer-load / pipelined small-tile loop)
     // and the one with the smallest modelled time wins: (workgroups per CU, rounded up) x tile area / efficiency.  The
     // model reproduces the measured ranking from 512^3 to 8192^3 (tools/gemm_bench.py; profiles/README.md): small and
     // awkward sizes prefer many small tiles (3072^3: 64x64 = 107 vs 88-92 TFLOP/s), 4096^3 and up the 256x256 tile.
@@ -748,7 +749,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const int64_t per_cu = (nblocks(bm, bn) + cus - 1) / cus;
                 return double(per_cu) * double(bm * bn) / eff;
             };
-            const double c256 = fused_extras ? 1e300 : cost(256, 256, 0.87), c128 = cost(128, 128, 0.78), c64 = cost(64, 64, 0.72);
+            const double c256 = fused_extras ? 1e300 : cost(256, 256, 0.88), c128 = cost(128, 128, 0.74), c64 = cost(64, 64, 0.85);
             tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
         }
         switch (tile) {

@@ -1,100 +1,122 @@
-"""Module system and the layers on the hot path.
+"""Module system and the layers on the hot path (the callers of SURVEY.md §8 row a13).
 
-Restates the reference's `lightgrad/nn.py`: `Module` keeps ordered registries of
-parameters and sub-modules filled by attribute assignment (nn.py:14-29),
-`parameters/named_parameters` walk own parameters first, then sub-modules
-(nn.py:31-45), `map_parameters` rebinds every parameter to `fn(p)` (how a model
-is moved to a backend: `model.map_parameters(lambda p: p.hip())`, nn.py:47-55),
-`load_parameters` accepts tensors of any backend or ndarrays (nn.py:57-76).
-`Linear` is `x @ W.T(1, 0) + b` with `xavier` init (nn.py:90-96); `LayerNorm`
-is the composite of nn.py:109-124.  `Conv2d` is CNN-only and out of scope.
+Public surface = the reference's `lightgrad/nn.py` (same method names, argument meaning and iteration order, so a
+training script written against lightgrad runs unchanged); the implementation is this repo's own:
+
+  * a module keeps ONE ordered table of children (`_children`: attribute name -> tensor or Module) that attribute
+    assignment maintains; every traversal is built on a single generator, `_leaves()`, which yields
+    (owner module, attribute name, qualified name, tensor) with a module's own tensors before those of its
+    sub-modules (the order of nn.py:31-45, which optimizers and the data-parallel bucket layout rely on);
+  * `parameters`, `named_parameters`, `map_parameters` (nn.py:47-55: `model.map_parameters(lambda p: p.hip())` is how
+    a model moves to a backend) and `load_parameters` (nn.py:57-76: tensors of any backend or ndarrays) are thin
+    loops over `_leaves()` - no per-method recursion;
+  * `Linear` / `LayerNorm` use a backend's fused tape op when the tensor class offers one (`linear`, `layer_norm` on
+    HipTensor) and the reference's composite expression (nn.py:96, :117-124) otherwise - identical values.
 """
 import numpy as np
 from .autograd import Tensor, AbstractTensor
 
 
+def _is_child(value) -> bool:
+    return isinstance(value, (AbstractTensor, Module))
+
+
 class Module(object):
 
     def __init__(self):
-        object.__setattr__(self, '_params', {})
-        object.__setattr__(self, '_modules', {})
+        object.__setattr__(self, "_children", {})
 
-    def forward(self, x):
-        raise NotImplementedError()
+    # ---- the call protocol ------------------------------------------------------------------------------------------
 
-    def __call__(self, *args, **kwargs):
-        return self.forward(*args, **kwargs)
+    def forward(self, *inputs):
+        raise NotImplementedError("%s does not implement forward()" % type(self).__name__)
 
-    def __setattr__(self, name, val):
-        if isinstance(val, (AbstractTensor, Module)):
-            self.register_param_or_module(name, val)
-        object.__setattr__(self, name, val)
+    def __call__(self, *inputs, **options):
+        return self.forward(*inputs, **options)
 
-    def register_param_or_module(self, name, val):
-        if isinstance(val, AbstractTensor):
-            self._params[name] = val
-        elif isinstance(val, Module):
-            self._modules[name] = val
-        return val
+    # ---- bookkeeping ------------------------------------------------------------------------------------------------
+
+    def __setattr__(self, name, value):
+        if _is_child(value):
+            self.register_param_or_module(name, value)
+        object.__setattr__(self, name, value)
+
+    def register_param_or_module(self, name, value):
+        """file a tensor / sub-module under `name` (re-assigning a name keeps its position in the table)"""
+        if _is_child(value):
+            self._children[name] = value
+        return value
 
     def unregister_param_or_module(self, name):
-        if name in self._params:
-            return self._params.pop(name)
-        if name in self._modules:
-            return self._modules.pop(name)
+        return self._children.pop(name, None)
+
+    def _own(self, kind):
+        return [(n, c) for n, c in self._children.items() if isinstance(c, kind)]
+
+    def _leaves(self, scope: str = "", sep: str = "."):
+        """every parameter below this module: (owner, attribute name, qualified name, tensor); own tensors first"""
+        for name, tensor in self._own(AbstractTensor):
+            yield self, name, scope + name, tensor
+        for name, sub in self._own(Module):
+            yield from sub._leaves(scope + name + sep, sep)
+
+    # ---- the reference's traversal API ------------------------------------------------------------------------------
 
     def parameters(self):
-        yield from self._params.values()
-        for m in self._modules.values():
-            yield from m.parameters()
+        return (leaf[3] for leaf in self._leaves())
 
     def named_parameters(self, prefix: str = "", separator: str = "."):
-        prefix = (prefix + separator) if len(prefix) > 0 else ""
-        for name, p in self._params.items():
-            yield (prefix + name, p)
-        for name, m in self._modules.items():
-            yield from m.named_parameters(prefix=prefix + name, separator=separator)
+        scope = prefix + separator if prefix else ""
+        return ((qualified, tensor) for _, _, qualified, tensor in self._leaves(scope, separator))
 
     def map_parameters(self, fn):
-        for key, tensor in list(self._params.items()):
-            self.__setattr__(key, fn(tensor))
-        for m in self._modules.values():
-            m.map_parameters(fn)
+        for owner, name, _, tensor in list(self._leaves()):
+            setattr(owner, name, fn(tensor))
         return self
 
-    def load_parameters(self, param_dict, prefix: str = "", separator: str = '.') -> None:
-        param_dict = dict(param_dict)
-        if len(prefix) > 0:
-            prefix += separator
-        for key, p in list(self._params.items()):
-            assert (prefix + key) in param_dict, "%s not found in param dict!" % (prefix + key)
-            new_p = param_dict[prefix + key]
-            if not isinstance(new_p, p.__class__):
-                new_p = new_p.numpy() if isinstance(new_p, AbstractTensor) else new_p
-                assert isinstance(new_p, np.ndarray), "Unexpected parameter type %s!" % new_p.__class__.__name__
-                new_p = p.__class__.from_numpy(new_p)
-            assert p.shape == new_p.shape, "Shapes do not align! (%s != %s)" % (p.shape, new_p.shape)
-            self.__setattr__(key, new_p)
-        for key, m in self._modules.items():
-            m.load_parameters(param_dict, prefix=prefix + key, separator=separator)
+    def load_parameters(self, param_dict, prefix: str = "", separator: str = ".") -> None:
+        source = dict(param_dict)
+        scope = prefix + separator if prefix else ""
+        for owner, name, qualified, current in list(self._leaves(scope, separator)):
+            if qualified not in source:
+                raise AssertionError("no entry %r among the parameters to load (have: %s)" % (qualified, sorted(source)))
+            setattr(owner, name, _as_tensor_like(current, source[qualified], qualified))
+
+
+def _as_tensor_like(current, incoming, what):
+    """`incoming` (tensor of any backend, or ndarray) as a tensor of `current`'s class; shapes must agree"""
+    if not isinstance(incoming, type(current)):
+        array = incoming.numpy() if isinstance(incoming, AbstractTensor) else incoming
+        if not isinstance(array, np.ndarray):
+            raise AssertionError("cannot load %r from a %s" % (what, type(incoming).__name__))
+        incoming = type(current).from_numpy(array)
+    if tuple(incoming.shape) != tuple(current.shape):
+        raise AssertionError("%r has shape %s, the value to load has %s" % (what, tuple(current.shape), tuple(incoming.shape)))
+    return incoming
 
 
 class ModuleList(Module, list):
+    """a python list whose entries are registered under their index (nn.py:78-88)"""
 
     def __init__(self, *elements):
         Module.__init__(self)
         list.__init__(self, elements)
-        for i, e in enumerate(elements):
-            self.register_param_or_module(str(i), e)
+        for index, element in enumerate(elements):
+            self.register_param_or_module(str(index), element)
 
-    def __setitem__(self, i, e):
-        assert i < len(self)
-        self.unregister_param_or_module(str(i))
-        self.register_param_or_module(str(i), e)
-        return list.__setitem__(self, i, e)
+    def __setitem__(self, index, element):
+        if not -len(self) <= index < len(self):
+            raise IndexError("ModuleList assignment index out of range")
+        index %= len(self)
+        # drop, then file again: like the reference (nn.py:84-88) a replaced entry moves to the END of the traversal
+        # order, which the per-parameter step count of Adam / AdaBelief (optim.py:36, :48) makes observable
+        self.unregister_param_or_module(str(index))
+        self.register_param_or_module(str(index), element)
+        list.__setitem__(self, index, element)
 
 
 class Linear(Module):
+    """y = x @ W^T + b with W of shape (out, in), both drawn by `xavier` (nn.py:90-96)"""
 
     def __init__(self, in_feats: int, out_feats: int, bias: bool = True):
         Module.__init__(self)
@@ -102,28 +124,31 @@ class Linear(Module):
         self.bias = Tensor.xavier((out_feats,)) if bias else None
 
     def forward(self, x):
-        if hasattr(x, "linear"):
-            # optional backend op: the same `x @ W.T(1, 0) + b` as one tape node (HipTensor: bias in the GEMM epilogue)
-            return x.linear(self.weight, self.bias) if self.bias is not None else x.linear(self.weight)
+        fused = getattr(x, "linear", None)
+        if fused is not None:        # one tape node, bias added in the GEMM epilogue (HipTensor)
+            return fused(self.weight) if self.bias is None else fused(self.weight, self.bias)
         y = x @ self.weight.T(1, 0)
-        return (y + self.bias) if self.bias is not None else y
+        return y if self.bias is None else y + self.bias
 
 
 class Conv2d(Module):
-    """ valid 2-d convolution with optional zero padding: `x.pad(p).conv(w, strides=s) + b` (reference nn.py:98-107) """
+    """valid 2-d convolution, zero padding of kernelsize // 2 unless told otherwise (nn.py:98-107; CNN tail of §8f)"""
 
     def __init__(self, in_channels: int, out_channels: int, kernelsize: int = 3, stride: int = 1, pad: int = None, bias: bool = True):
         Module.__init__(self)
         self.w = Tensor.xavier((out_channels, in_channels, kernelsize, kernelsize))
         self.b = Tensor.xavier((1, out_channels, 1, 1)) if bias else None
-        self.s, self.p = stride, (kernelsize // 2) if pad is None else pad
+        self.s = stride
+        self.p = kernelsize // 2 if pad is None else pad
 
     def forward(self, x):
-        y = (x.pad(self.p) if self.p > 0 else x).conv(self.w, strides=self.s)
-        return (y + self.b) if self.b is not None else y
+        padded = x.pad(self.p) if self.p > 0 else x
+        y = padded.conv(self.w, strides=self.s)
+        return y if self.b is None else y + self.b
 
 
 class LayerNorm(Module):
+    """normalise over the trailing `shape` axes, then scale and shift (nn.py:109-124)"""
 
     def __init__(self, shape: tuple, eps: float = 1e-5):
         Module.__init__(self)
@@ -133,12 +158,13 @@ class LayerNorm(Module):
         self.bias = Tensor.zeros(self.shape)
 
     def forward(self, x):
-        assert x.shape[-len(self.shape):] == self.shape, \
-            "Shape mismatch in layer norm! (%s <-> %s)" % (x.shape, self.shape)
-        if len(self.shape) == 1 and hasattr(x, "layer_norm"):
-            # optional backend op: the composite below over the last axis as one kernel (HipTensor)
-            return x.layer_norm(self.weight, self.bias, eps=self.eps)
-        axes = tuple(range(len(x.shape) - len(self.shape), len(x.shape)))
-        D = x - x.mean(axis=axes, keepdims=True)
-        V = (D * D).mean(axis=axes, keepdims=True)
-        return D / (V + self.eps).pow(1 / 2) * self.weight + self.bias
+        k = len(self.shape)
+        if tuple(x.shape[-k:]) != self.shape:
+            raise AssertionError("LayerNorm over %s applied to an input of shape %s" % (self.shape, tuple(x.shape)))
+        fused = getattr(x, "layer_norm", None)
+        if k == 1 and fused is not None:          # the composite below as one kernel (HipTensor)
+            return fused(self.weight, self.bias, eps=self.eps)
+        axes = tuple(range(len(x.shape) - k, len(x.shape)))
+        centred = x - x.mean(axis=axes, keepdims=True)
+        variance = (centred * centred).mean(axis=axes, keepdims=True)
+        return centred / (variance + self.eps).pow(1 / 2) * self.weight + self.bias

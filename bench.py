@@ -1,17 +1,24 @@
 """Benchmark of the north-star path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-One "step" = one MNIST-MLP training step (784->512->10, bias, batch 1024 PER GPU, loss.mse,
-AdaBelief lr 1e-3): forward, backward, gradient all-reduce over RCCL (N > 1), optimizer update.
-Inputs are synthetic and resident in HBM before the timed region.  `value` is the whole-job
-aggregate steps/s (N ranks x K steps / max-over-ranks wall time): weak scaling.
+N > 1 needs no external launcher: this process then only starts N fresh rank processes (lightgrad_amd/launch.py,
+one per GPU; it never initialises a GPU itself), passes rank 0's JSON line through and exits non-zero if any rank
+fails.  Launching the ranks with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` works
+as well (WORLD_SIZE is then already set and nothing is spawned).
 
-The same JSON line also carries BASELINE's second headline, the 4096^2 fp32 matmul
-forward+backward (`secondary`, replicas on every rank), the roofline of the dominant kernel
-(the MFMA SGEMM; measured with HIP events on the library's stream) and the CPU baseline
-(the numpy oracle timed on this host's cores; rank 0, N = 1 only).
+One "step" = one MNIST-MLP training step (784->512->10, bias, batch 1024 PER GPU, loss.mse, AdaBelief lr 1e-3):
+forward, backward, gradient all-reduce over RCCL (N > 1, overlapped with the tail of backward), optimizer update.
+Inputs are synthetic and resident in HBM before the timed region.  `value` is the whole-job aggregate steps/s
+(N ranks x K steps / max-over-ranks wall time): weak scaling.
+
+The same JSON line also carries BASELINE's second headline, the 4096^2 fp32 matmul forward+backward (`secondary`,
+replicas on every rank), the roofline of the dominant kernel (the MFMA SGEMM; HIP events on the library's stream),
+the eager-tape rate next to the graph-replay rate, and the CPU baseline (this repo's CpuTensor backend running the
+same training loop on this host's cores; rank 0, N = 1 only).
+
+`--dry-run` replaces the GPU work by a few CPU steps (CpuTensor + gloo): it exists to test the launcher, the rank
+environment and the exchange protocol on machines without GPUs and prints a line marked "dry_run".
 """
 import argparse
 import json
@@ -37,36 +44,137 @@ def parse():
     ap.add_argument("--matmul-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bert", action="store_true", help="skip the tiny-BERT forward+backward timing")
+    ap.add_argument("--no-extras", action="store_true", help="MLP step only: skip matmul / roofline / HBM / BERT / CPU legs")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
     ap.add_argument("--force-comm", action="store_true",
-                    help="exercise the multi-GPU code path (RCCL communicator, graph + eager all-reduce and optimizer) with world_size 1")
+                    help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
                     help="graph: the step's kernels are captured once in hipGraphs and replayed; eager: python tape every step")
+    ap.add_argument("--comm-dispatch", choices=["graph", "eager"], default="graph",
+                    help="N > 1: graph = the all-reduce is a forked branch INSIDE the captured step (no host call per step); "
+                         "eager = forward+backward replay from a graph, all-reduce and optimizer are host calls")
+    ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the GPU work (launcher / protocol test)")
+    ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before the self-launcher gives up")
     return ap.parse_args()
+
+
+def _launcher():
+    """lightgrad_amd/launch.py loaded by path: the parent of a multi-rank job imports nothing else of the package"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("lightgrad_launch", os.path.join(ROOT, "lightgrad_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  No HIP call has happened in this process.
+        sys.exit(_launcher().spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+        assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     else:
         world, rank = 1, 0
+    if args.dry_run:
+        return dry_rank(args, rank, world)
+    return gpu_rank(args, rank, world)
 
+
+# ---------------------------------------------------------------------------------------------------------- dry run
+def dry_rank(args, rank, world):
+    import numpy as np
+    import lightgrad_amd as light
+    from lightgrad_amd import CpuTensor
+    from lightgrad_amd.dist import GlooCommunicator, SingleProcess, DataParallel
+    if world > 1:
+        import torch.distributed as dist
+        from lightgrad_amd.dist import _c_stdout_to_stderr
+        with _c_stdout_to_stderr():              # gloo announces its connections on the C-level stdout
+            dist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]),
+                                    rank=rank, world_size=world)
+            comm = GlooCommunicator()
+            comm.barrier()
+    else:
+        comm = SingleProcess()
+
+    class MLP(light.nn.Module):
+        def __init__(self):
+            light.nn.Module.__init__(self)
+            self.l1, self.l2 = light.nn.Linear(64, 32), light.nn.Linear(32, 10)
+
+        def forward(self, x):
+            return self.l2(self.l1(x).relu())
+    np.random.seed(rank)                             # different on purpose: DataParallel broadcasts rank 0's weights
+    model = MLP()
+    dp = DataParallel(model.parameters(), comm, overlap=True)
+    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, grad_scale=dp.grad_scale)
+    rng = np.random.RandomState(1000 + rank)
+    x = CpuTensor.from_numpy(rng.uniform(0, 1, (32, 64)).astype(np.float32))
+    onehot = CpuTensor.from_numpy(np.eye(10, dtype=np.float32)[rng.randint(0, 10, 32)], requires_grad=False)
+
+    def step():
+        loss = light.loss.mse(model(x), onehot)
+        opt.zero_grad()
+        loss.backward()
+        dp.sync_gradients()
+        opt.step()
+        return loss
+    steps = min(args.steps, 20)
+    for _ in range(min(args.warmup, 3)):
+        step()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    comm.barrier()
+    mine = time.perf_counter() - t0
+    t = CpuTensor.from_numpy(np.asarray([mine], np.float32), requires_grad=False)
+    comm.allreduce_max_(t)
+    elapsed = float(t.numpy()[0])
+    rates = np.zeros(world, np.float32)
+    rates[rank] = steps / mine
+    rates = CpuTensor.from_numpy(rates, requires_grad=False)
+    comm.allreduce_sum_(rates)
+    digest = CpuTensor.from_numpy(np.asarray([dp.parameter_digest(), -dp.parameter_digest()], np.float32), requires_grad=False)
+    comm.allreduce_max_(digest)
+    dmax, dmin = digest.numpy()
+    assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged"
+    assert np.isfinite(loss.item())
+    if rank == 0:
+        print(json.dumps({"metric": "DRY_RUN_launcher_and_exchange_check_on_cpu", "dry_run": True, "value": round(world * steps / elapsed, 2),
+                          "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 3),
+                          "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "cpu stand-in: mlp_64x32x10 batch 32, CpuTensor + gloo", "parallelism": "dp%d" % world},
+                          "ranks": {"world_size": world, "communicator": type(comm).__name__, "communicator_ranks": comm.world_size,
+                                    "per_rank_steps_per_sec": [round(float(v), 2) for v in rates.numpy()],
+                                    "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else "external"}}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU ranks
+def gpu_rank(args, rank, world):
     if not os.path.exists(os.path.join(ROOT, "lightgrad_amd", "liblghip.so")) and rank == 0:
         import subprocess            # the built library normally travels with the tree; compile it if it did not
         subprocess.run(["make", "-C", os.path.join(ROOT, "lightgrad_amd", "csrc"), "-j", "8"], check=True, stdout=sys.stderr)
     import numpy as np
     import lightgrad_amd as light
-    from lightgrad_amd import HipTensor
-    from lightgrad_amd.autograd.hip import HipDevice, lib as L
+    from lightgrad_amd import HipTensor, CpuTensor
+    from lightgrad_amd.autograd.hip import HipDevice, HipGraph, lib as L
     from lightgrad_amd.dist import RcclCommunicator, SingleProcess, DataParallel
 
     lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
     info = HipDevice.info()
     multi = world > 1 or args.force_comm
     comm = RcclCommunicator(rank, world) if multi else SingleProcess()
+    # rocprofv3 (ROCm 7.2) faults in its HSA queue interceptor when a hipGraph's packet batch crosses the end of the
+    # 16384-packet AQL ring (profiles/README.md, r2): keep the number of replayed graph nodes small when it is attached
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
 
     def wall_max(seconds):
         """max over ranks (the slowest rank defines the job's time)"""
@@ -75,6 +183,16 @@ def main():
         t = HipTensor.from_numpy(np.asarray([seconds], np.float32), requires_grad=False)
         comm.allreduce_max_(t)
         return float(t.numpy()[0])
+
+    def gather(value):
+        """[value of rank 0, ..., value of rank world-1] on every rank"""
+        v = np.zeros(world, np.float32)
+        v[rank] = value
+        if not multi:
+            return [float(value)]
+        t = HipTensor.from_numpy(v, requires_grad=False)
+        comm.allreduce_sum_(t)
+        return [float(x) for x in t.numpy()]
 
     def fence():
         comm.barrier()
@@ -91,14 +209,17 @@ def main():
             return self.l2(self.l1(x.reshape(-1, 784)).relu())
 
     np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
-    model = MLP().map_parameters(lambda p: p.hip())
+    model = MLP()
+    w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
+    model.map_parameters(lambda p: p.hip())
     use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
-    dp = DataParallel(model.parameters(), comm, flatten=use_graph)
-    dp.always_sync = args.force_comm                 # world_size 1: still run the all-reduce
+    overlap = multi and not (use_graph and args.comm_dispatch == "eager")
+    dp = DataParallel(model.parameters(), comm, flatten=use_graph, overlap=overlap)
+    dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
     opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
                                 device_step=use_graph)
     if use_graph:
-        dp.attach(opt)                               # flat buckets: zero_grad = one fill, update = one launch
+        dp.attach(opt)                               # flat buckets: zero_grad = one flag, update = one launch
     rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
     x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
     x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
@@ -120,26 +241,35 @@ def main():
         return loss
 
     step = eager_step
+    comm_in_graph = False
     if use_graph:
-        from lightgrad_amd.autograd.hip import HipGraph
-        for _ in range(3):                       # eager: allocates optimizer state, fills the pool, loads kernels
-            eager_step()
+        for _ in range(3):                       # eager: allocates optimizer state, fills the pool, loads kernels, and
+            eager_step()                         # teaches DataParallel(overlap=True) where the last gradient write is
         n_params = len(opt.parameters)
-        if not multi:
-            g_all = HipGraph()
-            with g_all.capture():
-                graph_loss = eager_step()
+        g_all = None
+        if not multi or args.comm_dispatch == "graph":
+            # ONE graph for the whole step.  With a communicator the all-reduce is a forked branch of it: started on the
+            # communication stream after the last parameter-gradient kernel, joined before the optimizer kernel.
+            try:
+                g_all = HipGraph()
+                with g_all.capture():
+                    graph_loss = eager_step()
+                comm_in_graph = multi
+            except L.HipError as e:
+                if not multi:
+                    raise
+                sys.stderr.write("[bench] rank %d: capturing the collective failed (%s); using eager collectives\n" % (rank, e))
+                g_all = None
+                dp.set_overlap(False)
             opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
-
+        if g_all is not None:
             def step():
                 g_all.replay()
                 opt.on_graph_replay()
                 return graph_loss
         else:
-            # forward+backward replay from a graph; the RCCL all-reduce and the two optimizer launches (multi-tensor
-            # AdaBelief + step counter) follow as eager calls on the same stream.  A second graph for the optimizer was
-            # measured slower: at world_size 1 with the all-reduce forced, 9 590 steps/s with two graphs vs 10 100 like
-            # this (a graph launch costs more than two kernel launches).
+            # fallback (--comm-dispatch eager): forward+backward replay from a graph; the RCCL all-reduce and the optimizer
+            # launch follow as host calls on the same stream
             g_fb = HipGraph()
             with g_fb.capture():
                 graph_loss = forward_backward()
@@ -157,7 +287,9 @@ def main():
     for _ in range(args.steps):
         loss = step()
     fence()
-    elapsed = wall_max(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = wall_max(mine)
+    per_rank = gather(args.steps / mine)
     final_loss = loss.item()
     assert np.isfinite(final_loss), final_loss
     steps_per_s = world * args.steps / elapsed
@@ -167,6 +299,17 @@ def main():
         comm.allreduce_max_(d)
         dmax, dmin = d.numpy()
         assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
+
+    # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
+    eager_steps = max(10, min(args.steps, 100))
+    for _ in range(5):
+        eager_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(eager_steps):
+        eager_step()
+    fence()
+    eager_steps_per_s = world * eager_steps / wall_max(time.perf_counter() - t0)
 
     # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
     # computes and drops, is then not computed at all.  Reported next to `value`, never as `value`.
@@ -196,6 +339,46 @@ def main():
         data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
         opt.on_graph_replay(args.warmup + args.steps)
 
+    ranks_info = {"world_size": world, "communicator": type(comm).__name__,
+                  "communicator_ranks": comm.ranks_seen() if multi else 1,          # lg_comm_rank: what RCCL itself reports
+                  "per_rank_steps_per_sec": [round(v, 2) for v in per_rank],
+                  "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else
+                              ("torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"),
+                  "exchange": None if not multi else
+                              ("all-reduce forked inside the captured step, overlapped with the input-gradient GEMM" if comm_in_graph else
+                               ("host-launched all-reduce on the communication stream, overlapped" if dp.overlap else
+                                "host-launched all-reduce on the compute stream after backward"))}
+
+    out = {
+        "metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
+                   "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
+                   "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
+                   "input_requires_grad": True,
+                   "dispatch": "hipGraph replay (python tape captured once)" if use_graph else "eager python tape",
+                   "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
+        "final_loss": round(final_loss, 6),
+        "ranks": ranks_info,
+        "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),
+        "mlp_steps_per_sec_eager": round(eager_steps_per_s, 2),
+        "mlp_steps_per_sec_batch_as_data": None if data_input_steps_per_s is None else round(data_input_steps_per_s, 2),
+    }
+    if not args.no_extras:
+        out.update(extras(args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel,
+                          SingleProcess, wall_max, fence, under_profiler, w0, x_np, onehot_np))
+    if multi:
+        comm.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def extras(args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel, SingleProcess,
+           wall_max, fence, under_profiler, w0, x_np, onehot_np):
+    """everything besides the headline: 4096^2 matmul, roofline of the dominant kernel, HBM microbench, tiny-BERT, CPU baseline"""
+    import ctypes
+    import numpy as np
     # ------------------------------------------------------------------ 4096^2 matmul forward + backward
     np.random.seed(0)
     a = HipTensor.from_numpy(np.random.uniform(-1, 1, (MATMUL_N, MATMUL_N)).astype(np.float32))
@@ -218,8 +401,6 @@ def main():
     mm_tflops = world * args.matmul_iters * MATMUL_FLOP / mm_elapsed / 1e12
 
     # ------------------------------------------------------------------ roofline of the dominant kernel (HIP events)
-    import ctypes
-
     def event():
         e = ctypes.c_void_p()
         L.check(lib.lg_event_create(ctypes.byref(e)))
@@ -250,24 +431,32 @@ def main():
     for tag, (ta, tb) in {"NN": (0, 0), "NT": (0, 1), "TN": (1, 0)}.items():
         gemm_ms[tag] = time_launches(lambda: L.check(lib.lg_gemm_f32(ta, tb, n, n, n, a.ptr, n, 0, b.ptr, n, 0, c.ptr, n, 0, 1, 0)), 10)
     gemm_tf = {k: 2 * n ** 3 / (v * 1e-3) / 1e12 for k, v in gemm_ms.items()}
-    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (profiles/r1/pmc_traffic.json; separate runs,
+    # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (profiles/rN/pmc_traffic.json; separate runs,
     # corrected as MI355X_MICROARCH.md prescribes) - cannot be collected from inside this process
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get("sgemm_mfma_256x256_NN_4096", {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    for rnd in ("r2", "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
+                traffic = json.load(f).get("sgemm_mfma_256x256_NN_4096", {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                break
+        except (OSError, ValueError):
+            pass
     roofline = {"kernel": "sgemm_mfma<256,256,32,4,4> NN 4096^3 (forward GEMM of the matmul workload)", "bound": "mfma",
                 "achieved": round(gemm_tf["NN"], 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(gemm_tf["NN"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(gemm_ms["NN"], 4), "algorithmic_flop_per_launch": 2 * n ** 3}
-    # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache)
+    del c
+    # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache).  The
+    # operands hold RANDOM data (a 16 MiB random block repeated; constants switch fewer wires and read high)
     big = (16384, 8192)
     nbig = big[0] * big[1]
     p, q, r = (HipTensor.empty(big, requires_grad=False) for _ in range(3))
-    p.fill(0.5)
-    q.fill(0.25)
+    tile_n = 1 << 22
+    blk = np.random.RandomState(7 + rank).uniform(-1, 1, 2 * tile_n).astype(np.float32)
+    with light.no_grad():
+        p.reshape(nbig // tile_n, tile_n)[...] = HipTensor.from_numpy(blk[:tile_n], requires_grad=False)
+        q.reshape(nbig // tile_n, tile_n)[...] = HipTensor.from_numpy(blk[tile_n:], requires_grad=False)
     st = L.i64(p.strides)
     sh = L.i64(big)
     hbm = {}
@@ -279,7 +468,7 @@ def main():
         return lambda: L.check(lib.lg_ew(op, 2, sh, out.ptr, st, None, None, *args_, 0.0))
     for name, fn, bytes_per_elem in [("add", ew(L.EW_ADD, r, [p, q]), 12), ("mul", ew(L.EW_MUL, r, [p, q]), 12),
                                      ("relu", ew(L.EW_RELU, r, [p]), 8), ("exp", ew(L.EW_EXP, r, [p]), 8),
-                                     ("relu_bwd", ew(L.EW_RELU_BWD, r, [p, q]), 12), ("iadd", ew(L.EW_ADD, p, [p, q]), 12)]:
+                                     ("relu_bwd", ew(L.EW_RELU_BWD, r, [p, q]), 12), ("iadd", ew(L.EW_ADD, r, [r, q]), 12)]:
         ms = time_launches(fn, 5)
         hbm[name] = {"ms": round(ms, 4), "GB/s": round(nbig * bytes_per_elem / (ms * 1e-3) / 1e9, 1)}
     s_out = HipTensor.empty((), requires_grad=False)
@@ -291,10 +480,12 @@ def main():
     hbm["sum_axis0"] = {"ms": round(ms, 4), "GB/s": round(nbig * 4 / (ms * 1e-3) / 1e9, 1)}
     for v in hbm.values():
         v["frac_of_8TBs"] = round(v["GB/s"] / HBM_PEAK_GBS, 3)
+    hbm["operands"] = "random U(-1,1), 16 MiB block repeated"
     del p, q, r
 
     # ------------------------------------------------------------------ tiny-BERT forward + backward (BASELINE config #5)
     bert_ms = bert_graph_ms = None
+    bert_replays = 0
     try:
         if args.no_bert:
             raise RuntimeError("skipped (--no-bert)")
@@ -327,100 +518,110 @@ def main():
             fence()
             batches.append(time.perf_counter() - t0)
         bert_ms = 1e3 * wall_max(min(batches)) / 5
-        from lightgrad_amd.autograd.hip import HipGraph as _Graph
-        bgraph = _Graph()
+        bgraph = HipGraph()
         with bgraph.capture():
             bert_iter()
-        # few replays on purpose: rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch once ~16 000 graph kernel
-        # nodes have been replayed in one process (40 x this ~400-node graph; 3 replays are fine) - keep bench.py profilable
-        for _ in range(2):
+        # 50 timed replays; only 6 with rocprofv3 attached - its HSA queue interceptor faults once a graph's packet batch
+        # crosses the end of the 16384-packet AQL ring (evidence: profiles/README.md r2), un-profiled runs never do
+        bert_replays = 6 if under_profiler else 50
+        for _ in range(2 if under_profiler else 5):
             bgraph.replay()
         fence()
         t0 = time.perf_counter()
-        for _ in range(6):
+        for _ in range(bert_replays):
             bgraph.replay()
         fence()
-        bert_graph_ms = 1e3 * wall_max(time.perf_counter() - t0) / 6
+        bert_graph_ms = 1e3 * wall_max(time.perf_counter() - t0) / bert_replays
         bgraph.destroy()
         del bmodel
     except Exception as e:            # the BERT row is "next" scope: never let it take the headline numbers down
         bert_ms = "failed: %r" % (e,)
 
-    # ------------------------------------------------------------------ CPU baseline (oracle, host cores)
+    # ------------------------------------------------------------------ CPU baseline (host cores, rank 0 at N = 1)
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import np_oracle as O                       # the checker, timed here ONLY as the reported CPU baseline
-        w0, xc, tc, _ = O.synthetic_mlp_problem(0)
-        o_opt = O.make_optimizer("adabelief")
-        w = {k: v.copy() for k, v in w0.items()}
-        t0 = time.perf_counter()
-        n_cpu = 0
-        while time.perf_counter() - t0 < 10.0 and n_cpu < 2000:
-            _, grads, _ = O.mlp_loss_and_grads(w, xc, tc)
-            for name in O.PARAM_ORDER:
-                w[name] += o_opt.delta(name, grads[name])
-            n_cpu += 1
-        cpu_steps = n_cpu / (time.perf_counter() - t0)
-        an, bn = a.numpy(), b.numpy()
-        t0 = time.perf_counter()
-        O.matmul_fwd_bwd(an, bn)
-        cpu_mm = time.perf_counter() - t0
-        # the same step on ONE BLAS thread (SURVEY.md 8d asks for both): a short sample
-        one_thread = None
-        try:
-            from threadpoolctl import threadpool_limits
-            with threadpool_limits(limits=1):
-                t0 = time.perf_counter()
-                n1 = 0
-                while time.perf_counter() - t0 < 4.0 and n1 < 200:
-                    _, grads, _ = O.mlp_loss_and_grads(w, xc, tc)
-                    for name in O.PARAM_ORDER:
-                        w[name] += o_opt.delta(name, grads[name])
-                    n1 += 1
-                one_thread = round(n1 / (time.perf_counter() - t0), 2)
-        except Exception:            # threadpoolctl missing or BLAS not controllable: report the all-threads number only
-            one_thread = None
-        # `value` is the better of the two: at these shapes OpenBLAS on all 256 host threads is slower than on one
-        best_is_one = one_thread is not None and one_thread > cpu_steps
-        cpu_baseline = {"value": one_thread if best_is_one else round(cpu_steps, 2), "unit": "steps/s",
-                        "cores": 1 if best_is_one else os.cpu_count(), "kind": "port",
-                        "value_all_blas_threads": round(cpu_steps, 2), "value_one_blas_thread": one_thread,
-                        "host_cpus": os.cpu_count(),
-                        "sample": "%d MLP training steps (same shapes, numpy oracle, BLAS default threads) in ~10 s; "
-                                  "matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s" % (n_cpu, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
-                        "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3), "numpy": np.__version__}
+        cpu_baseline = cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b)
 
-    if multi:
-        comm.close()
-    if rank == 0:
-        out = {
-            "metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
-                       "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
-                       "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
-                       "input_requires_grad": True,
-                       "dispatch": ("hipGraph replay (python tape captured once)" if not multi else
-                                    "hipGraph replay of forward+backward, eager all-reduce and optimizer launches") if use_graph else "eager python tape",
-                       "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
-            "final_loss": round(final_loss, 6),
-            "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),
-            "mlp_steps_per_sec_batch_as_data": None if data_input_steps_per_s is None else round(data_input_steps_per_s, 2),
-            "secondary": {"metric": "matmul4096_fwd_bwd_tflops", "value": round(mm_tflops, 2), "unit": "TFLOP/s",
-                          "ms_per_iter": round(1e3 * mm_elapsed / args.matmul_iters, 4), "iters": args.matmul_iters,
-                          "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
-                          "scaling": "replicas", "gemm_kernel_tflops": {k: round(v, 2) for k, v in gemm_tf.items()}},
-            "tiny_bert_fwd_bwd": {"ms_per_iter": bert_ms if isinstance(bert_ms, str) else round(bert_ms, 3), "batch": 8, "seq_len": 128,
-                                  "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522; masked-LM cross-entropy over all 1024 positions",
-                                  "dispatch": "eager python tape",
-                                  "ms_per_iter_hipgraph": round(bert_graph_ms, 3) if bert_graph_ms else None},
-            "roofline": roofline,
-            "roofline_hbm": hbm,
-            "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(out))
+    return {
+        "secondary": {"metric": "matmul4096_fwd_bwd_tflops", "value": round(mm_tflops, 2), "unit": "TFLOP/s",
+                      "ms_per_iter": round(1e3 * mm_elapsed / args.matmul_iters, 4), "iters": args.matmul_iters,
+                      "flop_per_iter": MATMUL_FLOP, "frac_of_mfma_peak": round(mm_tflops / world / MFMA_F32_PEAK_TFLOPS, 4),
+                      "scaling": "replicas", "gemm_kernel_tflops": {k: round(v, 2) for k, v in gemm_tf.items()}},
+        "tiny_bert_fwd_bwd": {"ms_per_iter": bert_ms if isinstance(bert_ms, str) else round(bert_ms, 3), "batch": 8, "seq_len": 128,
+                              "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522; masked-LM cross-entropy over all 1024 positions",
+                              "dispatch": "eager python tape",
+                              "ms_per_iter_hipgraph": round(bert_graph_ms, 3) if bert_graph_ms else None,
+                              "hipgraph_replays_timed": bert_replays, "profiler_attached": under_profiler},
+        "roofline": roofline,
+        "roofline_hbm": hbm,
+        "cpu_baseline": cpu_baseline,
+    }
+
+
+def cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b):
+    """the CPU baseline is this repo's CpuTensor backend (pinned bit for bit to the reference's CPU
+    backend by tests/test_cpu_backend.py) running the SAME training loop through the python tape, on this host's cores;
+    BLAS on all threads and on one.  The tape-free numpy oracle is timed next to it as a second, friendlier figure."""
+    import numpy as np
+
+    class MLP(light.nn.Module):
+        def __init__(self):
+            light.nn.Module.__init__(self)
+            self.l1 = light.nn.Linear(784, 512)
+            self.l2 = light.nn.Linear(512, 10)
+
+        def forward(self, x):
+            return self.l2(self.l1(x.reshape(-1, 784)).relu())
+
+    def tape_loop(seconds, max_steps):
+        model = MLP()
+        model.load_parameters(w0)
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-3)
+        xc, tc = CpuTensor.from_numpy(x_np), CpuTensor.from_numpy(onehot_np)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds and n < max_steps:
+            loss = light.loss.mse(model(xc), tc)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            n += 1
+        assert np.isfinite(loss.item())
+        return n, n / (time.perf_counter() - t0)
+
+    n_all, all_threads = tape_loop(8.0, 2000)
+    one_thread = n_one = None
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            n_one, one_thread = tape_loop(6.0, 2000)
+    except Exception:                # threadpoolctl missing or BLAS not controllable: report the all-threads number only
+        pass
+    an, bn = CpuTensor.from_numpy(a.numpy()), CpuTensor.from_numpy(b.numpy())
+    t0 = time.perf_counter()
+    (an @ bn).backward(allow_fill=True)
+    cpu_mm = time.perf_counter() - t0
+    # the tape-free oracle (no python tape, no per-op dispatch): a second figure, never `value`
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import np_oracle as O                       # the checker, timed here ONLY as a reported CPU figure
+    o_opt = O.make_optimizer("adabelief")
+    w = {k: v.copy() for k, v in w0.items()}
+    t0, n_or = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 4.0 and n_or < 1000:
+        _, grads, _ = O.mlp_loss_and_grads(w, x_np, onehot_np)
+        for name in O.PARAM_ORDER:
+            w[name] += o_opt.delta(name, grads[name])
+        n_or += 1
+    oracle_rate = n_or / (time.perf_counter() - t0)
+    best_is_one = one_thread is not None and one_thread > all_threads
+    return {"value": round(one_thread if best_is_one else all_threads, 2), "unit": "steps/s",
+            "cores": 1 if best_is_one else os.cpu_count(), "kind": "port",
+            "what": "lightgrad_amd CpuTensor backend (numpy), same MLP training loop through the python tape",
+            "value_all_blas_threads": round(all_threads, 2), "value_one_blas_thread": None if one_thread is None else round(one_thread, 2),
+            "host_cpus": os.cpu_count(),
+            "sample": "%d steps in ~8 s on all BLAS threads%s; matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s"
+                      % (n_all, "" if n_one is None else ", %d steps in ~6 s on one" % n_one, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
+            "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3),
+            "oracle_tape_free_steps_per_sec": round(oracle_rate, 2), "numpy": np.__version__}
 
 
 if __name__ == "__main__":

@@ -5,8 +5,12 @@
  * The reference has no distributed code at all; this is the
  * MI355X-native addition for BASELINE config #4: one process per GPU, one
  * fp32 sum all-reduce per training step over a single flat gradient bucket,
- * enqueued on the compute stream of liblghip.so (lg_stream()) between
- * backward() and optim.step() with no host synchronisation.
+ * with no host synchronisation.  The exchange runs on the library's own
+ * communication stream, forked from the compute stream (lg_stream()) as soon
+ * as the last parameter gradient has been enqueued and joined before the
+ * optimizer (lg_comm_fork / lg_comm_allreduce_forked_f32 / lg_comm_join), so
+ * it overlaps the rest of backward; during lg_graph_begin .. lg_graph_end the
+ * same three calls are captured as a parallel branch of the hipGraph.
  *
  * Rendezvous: rank 0 calls lg_comm_get_unique_id and hands the 128 bytes to
  * the other ranks out of band (the launcher's file/pipe); no network service.
@@ -30,7 +34,13 @@ const char* lg_comm_last_error(void);
 int lg_comm_get_unique_id(char id[LG_COMM_ID_BYTES]);
 int lg_comm_init(int rank, int nranks, const char id[LG_COMM_ID_BYTES]);   /* lg_init must have been called */
 int lg_comm_rank(int* rank, int* nranks);
-int lg_comm_allreduce_f32(float* buf, int64_t n, int op);                  /* in place, stream-ordered */
+int lg_comm_allreduce_f32(float* buf, int64_t n, int op);                  /* in place, on the compute stream */
+/* overlap: fork = the communication stream waits for everything enqueued so far on the compute stream;
+ * allreduce_forked = the collective, in place, on the communication stream; join = the compute stream waits
+ * for everything enqueued so far on the communication stream.  No host synchronisation in any of them. */
+int lg_comm_fork(void);
+int lg_comm_allreduce_forked_f32(float* buf, int64_t n, int op);
+int lg_comm_join(void);
 int lg_comm_broadcast_f32(float* buf, int64_t n, int root);                /* in place, stream-ordered */
 int lg_comm_destroy(void);
 

@@ -101,6 +101,9 @@ COMM_PROTOTYPES = {
     "lg_comm_init": (c_int, [c_int, c_int, c_void_p]),
     "lg_comm_rank": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "lg_comm_allreduce_f32": (c_int, [c_void_p, c_int64, c_int]),
+    "lg_comm_fork": (c_int, []),
+    "lg_comm_allreduce_forked_f32": (c_int, [c_void_p, c_int64, c_int]),
+    "lg_comm_join": (c_int, []),
     "lg_comm_broadcast_f32": (c_int, [c_void_p, c_int64, c_int]),
     "lg_comm_destroy": (c_int, []),
 }
@@ -137,7 +140,11 @@ def lib():
         if n.value < 1:
             raise HipError("no HIP device visible: the HipTensor backend needs an MI355X (gfx950); "
                            "there is no CPU fallback - use CpuTensor explicitly for host execution")
-        device = int(os.environ.get("LIGHTGRAD_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))) % n.value
+        device = int(os.environ.get("LIGHTGRAD_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if not 0 <= device < n.value:
+            # never wrap around: two ranks on one GPU make RCCL report a duplicate device or hang
+            raise HipError("this process is bound to HIP device %d (LIGHTGRAD_HIP_DEVICE / LOCAL_RANK) but only %d device(s) "
+                           "are visible: start at most one rank per GPU" % (device, n.value))
         rc = handle.lg_init(device)
         if rc != 0:
             raise HipError("lg_init(%d) failed: %s" % (device, handle.lg_last_error().decode()))

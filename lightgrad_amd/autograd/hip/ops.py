@@ -10,7 +10,8 @@ import builtins as _py      # this module defines ops named max / min / sum / po
 import ctypes
 import numpy as np
 from ..func import Function
-from .tensor import HipTensor, HipBuffer, contiguous_strides
+import weakref
+from .tensor import HipTensor, HipBuffer, contiguous_strides, flush_lazy_readers
 from . import lib as _l
 from .lib import i64
 
@@ -52,6 +53,8 @@ def _bstrides(t, shape):
 def _ew(op, shape, ins, scalar=0.0, n_out=1, out=None):
     """enqueue one lg_ew call; `ins` holds HipTensors or None (= the scalar operand)"""
     L = _l.lib()
+    if out is not None:
+        flush_lazy_readers(out)          # writing into existing storage: lazy tensors defined from it are computed first
     outs = [out] if out is not None else [HipTensor.empty(shape) for _ in range(n_out)]
     args = []
     for k in range(4):
@@ -331,6 +334,7 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
         # C += A @ B straight into an existing dense buffer (a parameter's gradient): no temporary, no add pass
         assert not out_colmajor and bias is None and not batch_shape
         assert accumulate_into._shape == out_shape and accumulate_into.is_contiguous() and accumulate_into._dtype == _F32
+        flush_lazy_readers(accumulate_into)
         out = accumulate_into
     elif out_colmajor:
         out = HipTensor.empty(batch_shape + (N, M))
@@ -409,6 +413,9 @@ def _gemm_rowsum(a, b, accumulate_into=None, overwrite=False, rowsum_into=None, 
     ma, mb = _as_mat(a), _as_mat(b)
     for t, shape in ((accumulate_into, (M, N)), (rowsum_into, (M,))):
         assert t is None or (t._shape == shape and t.is_contiguous() and t._dtype == _F32)
+    for t in (accumulate_into, rowsum_into):
+        if t is not None:
+            flush_lazy_readers(t)
     out = accumulate_into if accumulate_into is not None else HipTensor.empty((M, N))
     rowsum = rowsum_into if rowsum_into is not None else HipTensor.empty((M,))
     _l.check(_l.lib().lg_gemm_rowsum_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K, ma.t.ptr, ma.ld, mb.t.ptr, mb.ld,
@@ -425,6 +432,9 @@ def _gemm_fused(a, b, bias=None, accumulate_into=None, overwrite=False, rowsum_i
     (M, K), (K2, N) = a._shape, b._shape
     assert K == K2 and M > 0 and N > 0
     ma, mb = _as_mat(a), _as_mat(b)
+    for t in (accumulate_into, rowsum_into):
+        if t is not None:
+            flush_lazy_readers(t)
     out = accumulate_into if accumulate_into is not None else HipTensor.empty((M, N))
     assert out._shape == (M, N) and out.is_contiguous()
     rowsum = None
@@ -491,9 +501,11 @@ class dot(Function):
             acc_a, acc_b = a._grad_accumulator(), b._grad_accumulator()
             if a.requires_grad and acc_a is not None and acc_a.is_contiguous() and a is not b:
                 _gemm(out_grad, _swap_last(b), accumulate_into=acc_a, overwrite=a._consume_zero_pending())
+                a._notify_grad_written()
                 ga = False
             if b.requires_grad and acc_b is not None and acc_b.is_contiguous() and a is not b:
                 _gemm(_swap_last(a), out_grad, accumulate_into=acc_b, overwrite=b._consume_zero_pending())
+                b._notify_grad_written()
                 gb = False
         if ga is None:
             ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
@@ -546,6 +558,7 @@ def _value_bits(val, dtype):
 class fill(Function):
     """ opencl/ops.py:172-177; works on strided views and any dtype """
     def forward(ctx, t, val):
+        flush_lazy_readers(t)
         _l.check(_l.lib().lg_fill_strided(t._dtype.itemsize, len(t._shape), i64(t._shape), t.ptr, i64(t._strides),
                                           _value_bits(val, t._dtype)))
         return t
@@ -589,6 +602,13 @@ class relu(Function):
         if t.is_contiguous() and t.numel() > 0:
             out = HipTensor(None, t._shape, None, 0, t._dtype)
             out._lazy_source = ("relu", t)
+            # whoever writes into t's storage before `out` has been computed computes it first (flush_lazy_readers)
+            buf = t.data
+            if buf.lazy_readers is None:
+                buf.lazy_readers = []
+            elif len(buf.lazy_readers) >= 64:        # a tensor nobody ever writes (relu of a constant, step after step)
+                buf.lazy_readers = [r for r in buf.lazy_readers if r() is not None and r()._data is None]
+            buf.lazy_readers.append(weakref.ref(out))
             return out
         return _unary(_l.EW_RELU, t)
 
@@ -655,6 +675,7 @@ class getitem(Function):
                 if table._consume_zero_pending():
                     acc.fill(0)
                 _scatter_add_rows(shape, idx, out_grad, into=acc)
+                table._notify_grad_written()
                 return None
             return _scatter_add_rows(shape, idx, out_grad)
         grad = HipTensor.zeros(shape, dtype=out_grad._dtype, requires_grad=False)
@@ -666,6 +687,7 @@ class getitem(Function):
 class setitem(Function):
     """ strided copy / fill into the indexed view (opencl/ops.py:331-340) """
     def forward(ctx, a, idx, val):
+        flush_lazy_readers(a)
         view = _idx_view(a, idx)
         if isinstance(val, np.ndarray) and val.ndim > 0:
             val = HipTensor.from_numpy(val.astype(a._dtype), requires_grad=False)
@@ -701,6 +723,7 @@ def _reduce_into(acc, x, axes, overwrite=False):
         mask |= 1 << a
     kept = tuple(s for i, s in enumerate(x._shape) if i not in axes)
     assert acc._shape == kept and acc.is_contiguous()
+    flush_lazy_readers(acc)
     _l.check(_l.lib().lg_reduce_acc(_l.RED_SUM, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, acc.ptr,
                                     0 if overwrite else 1))
 
@@ -872,17 +895,23 @@ class linear(Function):
                                         rowsum_into=acc_b, rowsum_overwrite=acc_b is not None and bias._consume_zero_pending())
             dw = out_w if acc_w is None else None
             db = out_b if acc_b is None else None
+            if acc_w is not None:
+                weight._notify_grad_written()
+            if acc_b is not None:
+                bias._notify_grad_written()
             want_db = False
         elif weight.requires_grad:
             acc = weight._grad_accumulator()
             if acc is not None and acc.is_contiguous():
                 _gemm(_swap_last(g2), x2, accumulate_into=acc, overwrite=weight._consume_zero_pending())
+                weight._notify_grad_written()
             else:
                 dw = _gemm(_swap_last(g2), x2)
         if x.requires_grad:
             acc = x._grad_accumulator()
             if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
                 _gemm(g2, weight, accumulate_into=acc, overwrite=x._consume_zero_pending())
+                (x._view_of_leaf if (x._view_of_leaf is not None and x._grad is None) else x)._notify_grad_written()
             else:
                 dx = _gemm(g2, weight).reshape(*x._shape)
         if not has_bias:
@@ -891,6 +920,7 @@ class linear(Function):
             acc = bias._grad_accumulator()
             if acc is not None and acc.is_contiguous():
                 _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())
+                bias._notify_grad_written()
             else:
                 db = _reduce(_l.RED_SUM, g2, (0,), False)
         return dx, dw, db
@@ -912,8 +942,12 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
                                    want_rowsum=want_db, rowsum_into=acc_b,
                                    rowsum_overwrite=acc_b is not None and bias._consume_zero_pending())
         dw = out_w if acc_w is None else None
+        if acc_w is not None:
+            weight._notify_grad_written()
         if want_db:
             db = out_b if acc_b is None else None
+            if acc_b is not None:
+                bias._notify_grad_written()
             want_db = False
     if x.requires_grad:
         dx = _gemm(g2, weight)
@@ -923,6 +957,7 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
         acc = bias._grad_accumulator()
         if acc is not None and acc.is_contiguous():
             _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())
+            bias._notify_grad_written()
         else:
             db = _reduce(_l.RED_SUM, g2, (0,), False)
     return dx, dw, db
@@ -1005,12 +1040,19 @@ class layer_norm(Function):
         acc_b = bias._grad_accumulator() if bias.requires_grad else None
         acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
         acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+        for t in (acc_w, acc_b):
+            if t is not None:
+                flush_lazy_readers(t)
         dw = acc_w if acc_w is not None else HipTensor.empty((cols,))
         db = acc_b if acc_b is not None else HipTensor.empty((cols,))
         _l.check(_l.lib().lg_layernorm_param_grads_f32(
             g.ptr, xhat.ptr, dw.ptr, db.ptr, rows, cols,
             1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
             1 if (acc_b is not None and not bias._consume_zero_pending()) else 0))
+        if acc_w is not None:
+            weight._notify_grad_written()
+        if acc_b is not None:
+            bias._notify_grad_written()
         return dx, (None if acc_w is not None else dw), (None if acc_b is not None else db)
 
 
@@ -1028,6 +1070,8 @@ def _gather_rows(table, ids):
 
 
 def _scatter_add_rows(shape, ids, out_grad, into=None):
+    if into is not None:
+        flush_lazy_readers(into)
     grad = into if into is not None else HipTensor.zeros(shape, requires_grad=False)
     ids, g = ids.contiguous(), out_grad.contiguous()
     row_len = 1
@@ -1068,5 +1112,6 @@ def adam_step_(p, g, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, gscale=1.0, be
     _require_f32(p, g, m, v)
     for t in (p, g, m, v):
         assert t.is_contiguous() and t._shape == p._shape, "adam_step_ needs dense tensors of one shape"
+    flush_lazy_readers(p)
     _l.check(_l.lib().lg_adam_step_f32(p.ptr, g.ptr, m.ptr, v.ptr, p.numel(), lr, b1, b2, eps, inv_bias1, inv_bias2, gscale,
                                        1 if belief else 0))

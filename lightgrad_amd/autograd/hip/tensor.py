@@ -38,10 +38,11 @@ def contiguous_strides(shape):
 
 class HipBuffer(object):
     """Owner of one pool allocation; returned to the pool when the last tensor viewing it dies."""
-    __slots__ = ("ptr", "nbytes", "__weakref__")
+    __slots__ = ("ptr", "nbytes", "lazy_readers", "__weakref__")
 
     def __init__(self, nbytes):
         self.ptr = None
+        self.lazy_readers = None      # weak references to lazy tensors that will still READ this block (see flush_lazy_readers)
         p = ctypes.c_void_p()
         _l.check(_l.lib().lg_malloc(ctypes.byref(p), max(int(nbytes), 1)))
         self.ptr = p.value
@@ -51,6 +52,21 @@ class HipBuffer(object):
         ptr, self.ptr = self.ptr, None
         if ptr is not None and _l._lib is not None:
             _l._lib.lg_free(ptr)
+
+
+def flush_lazy_readers(t) -> None:
+    """call before any kernel WRITES into storage that already exists (in-place operators, fill, setitem, uploads,
+    accumulating epilogues, optimizer updates, collectives): lazy tensors that were defined from the block's current
+    contents (`relu` of a dense tensor, see HipTensor._lazy_source) are computed first, so that - like the reference,
+    which evaluates relu at once (cpu/ops.py:226) - a later in-place change of the source never shows in them.
+    Costs one attribute test when nobody is waiting (the normal case)."""
+    buf = t._data
+    if buf is not None and buf.lazy_readers:
+        waiting, buf.lazy_readers = buf.lazy_readers, None
+        for ref in waiting:
+            reader = ref()
+            if reader is not None and reader._data is None:
+                reader._materialize()
 
 
 class PendingUpload(object):
@@ -267,6 +283,7 @@ class HipTensor(AbstractTensor):
         if not a.flags["C_CONTIGUOUS"]:
             a = a.copy(order="C")
         if a.nbytes > 0:
+            flush_lazy_readers(self)
             _l.check(_l.lib().lg_memcpy_h2d_async(self.ptr, a.ctypes.data, a.nbytes))
         return self
 
@@ -287,6 +304,7 @@ class HipTensor(AbstractTensor):
         assert self.is_contiguous() and pending.shape == self._shape and pending.dtype == self._dtype, \
             "commit_: need a dense tensor of shape %s / dtype %s" % (pending.shape, pending.dtype)
         assert pending.slot >= 0, "this prefetch has already been committed"
+        flush_lazy_readers(self)
         _l.check(_l.lib().lg_prefetch_commit(pending.slot, self.ptr, pending.nbytes))
         pending.slot, pending.keepalive = -1, None
         return self
@@ -345,6 +363,7 @@ class HipTensor(AbstractTensor):
     def _fused_adam_step(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief):
         """optional optimizer hook (optim.Adam(fused=True)): one kernel instead of ~14 elementwise launches"""
         from .ops import adam_step_
+        flush_lazy_readers(self)
         adam_step_(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief)
 
     def _fused_mse(self, y_hat):
@@ -362,6 +381,7 @@ class HipTensor(AbstractTensor):
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         assert offsets[-1] == self.numel()
+        flush_lazy_readers(self)
         _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
                                                 lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 0))
         # advance = 0: the ticket form (the last working workgroup increments the counter) costs one contended atomic per
@@ -377,6 +397,7 @@ class HipTensor(AbstractTensor):
         """like `_fused_adam_step`, but t = step_counter * t_mul + t_add is evaluated on the device"""
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
+        flush_lazy_readers(self)
         _l.check(_l.lib().lg_adam_step_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, self.numel(), lr, b1, b2, eps,
                                                step_counter.ptr, t_mul, t_add, grad_scale, 1 if belief else 0))
 

@@ -44,6 +44,11 @@ class AbstractTensor(metaclass=_TensorType):
     # fill(0) followed by +=, one pass over the buffer less.
     _grad_zero_pending = False
 
+    # Optional callable(tensor) invoked every time a gradient contribution for this LEAF has been written or enqueued
+    # (`add_grad`, or a backward kernel that accumulated straight into `_grad_accumulator()`).  dist.DataParallel sets
+    # it on parameters to start the gradient exchange as soon as the last one is there, while backward still runs.
+    _grad_written_hook = None
+
     def __init__(self, data, requires_grad: bool = True) -> None:
         self._data = data
         self._grad = None
@@ -178,6 +183,13 @@ class AbstractTensor(metaclass=_TensorType):
                 self._grad += grad
         finally:
             Gradients.enable()
+        if self._grad_written_hook is not None:
+            self._grad_written_hook(self)
+
+    def _notify_grad_written(self) -> None:
+        """for backward ops that accumulated into `_grad_accumulator()` themselves and report None (func.py extension)"""
+        if self._grad_written_hook is not None:
+            self._grad_written_hook(self)
 
     def _grad_accumulator(self):
         """The gradient buffer a backward op may add into directly, or None.  Only LEAF tensors that already own a

@@ -12,6 +12,12 @@
 static thread_local char g_cerr[1024] = "";
 static ncclComm_t g_comm = nullptr;
 static int g_rank = -1, g_nranks = 0;
+// The gradient exchange runs on its own stream, forked from and joined to the compute stream with events, so that
+// it overlaps the backward kernels still to come (the input-gradient GEMM of the first layer).  While the compute
+// stream is being captured the two event hand-offs pull this stream into the capture: the collective becomes a
+// parallel branch of the hipGraph and a replayed step costs no host call for it.
+static hipStream_t g_comm_stream = nullptr;
+static hipEvent_t  g_fork_ev = nullptr, g_join_ev = nullptr;
 
 static void cerr(const char* fmt, ...) {
     va_list ap;
@@ -19,6 +25,15 @@ static void cerr(const char* fmt, ...) {
     vsnprintf(g_cerr, sizeof(g_cerr), fmt, ap);
     va_end(ap);
 }
+
+#define LG_CHIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            cerr("%s: %s failed: %s", __func__, #expr, hipGetErrorString(_e));         \
+            return LG_EHIP;                                                            \
+        }                                                                              \
+    } while (0)
 
 #define LG_NCCL(expr)                                                                  \
     do {                                                                               \
@@ -53,6 +68,29 @@ int lg_comm_init(int rank, int nranks, const char id[LG_COMM_ID_BYTES]) {
     LG_NCCL(ncclCommInitRank(&g_comm, nranks, uid, rank));
     g_rank = rank;
     g_nranks = nranks;
+    if (!g_comm_stream) {
+        int lo = 0, hi = 0;                     // numerically lowest = highest priority: the few workgroups of the
+        LG_CHIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // collective get their CUs while a GEMM fills the chip
+        LG_CHIP(hipStreamCreateWithPriority(&g_comm_stream, hipStreamNonBlocking, hi));
+        LG_CHIP(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
+        LG_CHIP(hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming));
+    }
+    return LG_OK;
+}
+
+int lg_comm_fork(void) {
+    if (!g_comm) { cerr("lg_comm_fork: communicator not initialised"); return LG_ENOTINIT; }
+    hipStream_t compute = static_cast<hipStream_t>(lg_stream());
+    LG_CHIP(hipEventRecord(g_fork_ev, compute));
+    LG_CHIP(hipStreamWaitEvent(g_comm_stream, g_fork_ev, 0));
+    return LG_OK;
+}
+
+int lg_comm_join(void) {
+    if (!g_comm) { cerr("lg_comm_join: communicator not initialised"); return LG_ENOTINIT; }
+    hipStream_t compute = static_cast<hipStream_t>(lg_stream());
+    LG_CHIP(hipEventRecord(g_join_ev, g_comm_stream));
+    LG_CHIP(hipStreamWaitEvent(compute, g_join_ev, 0));
     return LG_OK;
 }
 
@@ -63,14 +101,21 @@ int lg_comm_rank(int* rank, int* nranks) {
     return LG_OK;
 }
 
-int lg_comm_allreduce_f32(float* buf, int64_t n, int op) {
-    if (!g_comm) { cerr("lg_comm_allreduce_f32: communicator not initialised"); return LG_ENOTINIT; }
-    if (n < 0 || (n > 0 && !buf)) { cerr("lg_comm_allreduce_f32: bad buffer"); return LG_EINVAL; }
-    if (op != LG_COMM_SUM && op != LG_COMM_MAX) { cerr("lg_comm_allreduce_f32: unknown op %d", op); return LG_EINVAL; }
+static int allreduce_on(hipStream_t stream, float* buf, int64_t n, int op, const char* who) {
+    if (!g_comm) { cerr("%s: communicator not initialised", who); return LG_ENOTINIT; }
+    if (n < 0 || (n > 0 && !buf)) { cerr("%s: bad buffer", who); return LG_EINVAL; }
+    if (op != LG_COMM_SUM && op != LG_COMM_MAX) { cerr("%s: unknown op %d", who, op); return LG_EINVAL; }
     if (n == 0) return LG_OK;
-    LG_NCCL(ncclAllReduce(buf, buf, size_t(n), ncclFloat32, op == LG_COMM_SUM ? ncclSum : ncclMax, g_comm,
-                          static_cast<hipStream_t>(lg_stream())));
+    LG_NCCL(ncclAllReduce(buf, buf, size_t(n), ncclFloat32, op == LG_COMM_SUM ? ncclSum : ncclMax, g_comm, stream));
     return LG_OK;
+}
+
+int lg_comm_allreduce_f32(float* buf, int64_t n, int op) {
+    return allreduce_on(static_cast<hipStream_t>(lg_stream()), buf, n, op, "lg_comm_allreduce_f32");
+}
+
+int lg_comm_allreduce_forked_f32(float* buf, int64_t n, int op) {
+    return allreduce_on(g_comm_stream, buf, n, op, "lg_comm_allreduce_forked_f32");
 }
 
 int lg_comm_broadcast_f32(float* buf, int64_t n, int root) {
@@ -84,6 +129,7 @@ int lg_comm_broadcast_f32(float* buf, int64_t n, int root) {
 int lg_comm_destroy(void) {
     if (!g_comm) return LG_OK;
     (void)hipStreamSynchronize(static_cast<hipStream_t>(lg_stream()));
+    if (g_comm_stream) (void)hipStreamSynchronize(g_comm_stream);
     LG_NCCL(ncclCommDestroy(g_comm));
     g_comm = nullptr;
     g_rank = -1;

@@ -38,6 +38,15 @@ class Communicator(object):
     def barrier(self):
         raise NotImplementedError()
 
+    # overlap protocol (DataParallel(overlap=True)): `fork` lets the communicator's own stream wait for the gradient
+    # kernels enqueued so far, `allreduce_sum_(flat, forked=True)` runs there, `join` makes the compute stream wait
+    # for it.  Communicators without streams (host collectives) run the collective at once and ignore fork / join.
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
     def close(self):
         pass
 
@@ -45,10 +54,11 @@ class Communicator(object):
 class SingleProcess(Communicator):
     """world_size 1: every collective is the identity"""
 
-    def allreduce_sum_(self, flat):
+    def allreduce_sum_(self, flat, forked=False):
         return flat
 
-    allreduce_max_ = allreduce_sum_
+    def allreduce_max_(self, flat):
+        return flat
 
     def broadcast_(self, flat, root=0):
         return flat
@@ -71,7 +81,7 @@ class GlooCommunicator(Communicator):
         assert isinstance(flat, CpuTensor) and flat.data.flags["C_CONTIGUOUS"]
         return torch.from_numpy(flat.data)     # shares memory: the reduction lands in the bucket
 
-    def allreduce_sum_(self, flat):
+    def allreduce_sum_(self, flat, forked=False):
         self._dist.all_reduce(self._tensor(flat), op=self._dist.ReduceOp.SUM)
         return flat
 
@@ -137,7 +147,9 @@ class RcclCommunicator(Communicator):
         self._L = L
         self._lib = L.comm_lib()
         if id_path is None:
-            # all ranks of one launch are children of the same launcher process (torch.distributed.run agent):
+            id_path = os.environ.get("LIGHTGRAD_RCCL_ID_FILE")      # set per job by lightgrad_amd.launch
+        if id_path is None:
+            # under torch.distributed.run: all ranks of one launch are children of the same launcher process (torch.distributed.run agent):
             # its pid makes the rendezvous file unique per launch, so a stale file of a crashed run is never read
             tag = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.getppid())
             id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lightgrad_rccl_%s.id" % tag)
@@ -161,12 +173,28 @@ class RcclCommunicator(Communicator):
 
     def _check_flat(self, flat):
         assert isinstance(flat, HipTensor) and flat.is_contiguous() and flat.dtype == np.float32
+        from .autograd.hip.tensor import flush_lazy_readers
+        flush_lazy_readers(flat)        # collectives write in place
         return flat
 
-    def allreduce_sum_(self, flat):
+    def allreduce_sum_(self, flat, forked=False):
         self._check_flat(flat)
-        self._L.comm_check(self._lib.lg_comm_allreduce_f32(flat.ptr, flat.numel(), 0))
+        fn = self._lib.lg_comm_allreduce_forked_f32 if forked else self._lib.lg_comm_allreduce_f32
+        self._L.comm_check(fn(flat.ptr, flat.numel(), 0))
         return flat
+
+    def fork(self):
+        self._L.comm_check(self._lib.lg_comm_fork())
+
+    def join(self):
+        self._L.comm_check(self._lib.lg_comm_join())
+
+    def ranks_seen(self) -> int:
+        """number of ranks the RCCL communicator itself reports (lg_comm_rank)"""
+        r, n = ctypes.c_int(-1), ctypes.c_int(0)
+        self._L.comm_check(self._lib.lg_comm_rank(ctypes.byref(r), ctypes.byref(n)))
+        assert r.value == self.rank
+        return n.value
 
     def allreduce_max_(self, flat):
         self._check_flat(flat)
@@ -216,9 +244,19 @@ class DataParallel(object):
         optim.zero_grad(); loss.backward(); dp.sync_gradients(); optim.step()
     """
 
-    def __init__(self, parameters, comm: Communicator, broadcast_parameters: bool = True, flatten: bool = False):
+    def __init__(self, parameters, comm: Communicator, broadcast_parameters: bool = True, flatten: bool = False,
+                 overlap: bool = False):
         self.parameters = tuple(parameters)
         self.comm = comm
+        # overlap=True: start the all-reduce on the communicator's own stream as soon as the LAST parameter gradient of
+        # the step has been enqueued, instead of after backward() - on the MLP that is before the input-gradient GEMM
+        # of the first layer, which then runs concurrently with the exchange.  "Last" is learnt, not guessed: the first
+        # step counts the gradient-written notifications of a whole backward pass (a static graph writes the same number
+        # every step) and exchanges the plain way; from then on the count reaching that number triggers the exchange.
+        # A step that writes fewer falls back to the plain way at sync_gradients() and re-learns; one that writes
+        # MORE - a gradient landing in the bucket while it is being reduced - is an error and raises.
+        self.overlap = bool(overlap)
+        self._writes_expected, self._writes_seen, self._exchange_started = None, 0, False
         assert len(self.parameters) > 0
         cls = self.parameters[0].__class__
         shapes = [p.shape for p in self.parameters]
@@ -240,6 +278,36 @@ class DataParallel(object):
                     p._data, p._offset, p._strides = v._data, v._offset, v._strides
         if broadcast_parameters and comm.world_size > 1:
             self.broadcast_parameters()
+        if self.overlap:
+            for p in self.parameters:
+                p._grad_written_hook = self._on_grad_written
+
+    def _exchange_needed(self) -> bool:
+        return self.comm.world_size > 1 or getattr(self, "always_sync", False)
+
+    def _on_grad_written(self, p) -> None:
+        if self._exchange_started:
+            raise RuntimeError("DataParallel(overlap=True): a parameter gradient was written after the gradient exchange of "
+                               "this step had started (%d writes expected) - the backward graph changed; call "
+                               "reset_overlap() before a step with a different graph" % self._writes_expected)
+        self._writes_seen += 1
+        if self._writes_seen == self._writes_expected and self._exchange_needed():
+            for q in self.parameters:
+                q._materialize_zero_grad()    # a lazily zeroed gradient no kernel has written (optim.zero_grad)
+            self.comm.fork()
+            self.comm.allreduce_sum_(self.bucket, forked=True)
+            self._exchange_started = True
+
+    def set_overlap(self, enabled: bool) -> None:
+        """switch the overlapped exchange on or off (off: one all-reduce on the compute stream in sync_gradients())"""
+        self.overlap = bool(enabled)
+        for p in self.parameters:
+            p._grad_written_hook = self._on_grad_written if self.overlap else None
+        self.reset_overlap()
+
+    def reset_overlap(self) -> None:
+        """forget the learnt write count (the next step exchanges after backward and learns again)"""
+        self._writes_expected, self._writes_seen, self._exchange_started = None, 0, False
 
     def attach(self, optimizer):
         """hand the flat buckets to an optimizer that can use them (one fill for zero_grad, one launch for step)"""
@@ -261,10 +329,18 @@ class DataParallel(object):
 
     def sync_gradients(self):
         """sum the gradient bucket over all ranks, in place, asynchronously"""
-        if self.comm.world_size > 1 or getattr(self, "always_sync", False):
-            for p in self.parameters:
-                p._materialize_zero_grad()        # a lazily zeroed gradient no kernel has written yet (optim.zero_grad)
-            self.comm.allreduce_sum_(self.bucket)
+        started, seen = self._exchange_started, self._writes_seen
+        self._writes_seen, self._exchange_started = 0, False
+        if not self._exchange_needed():
+            return
+        if started:
+            self.comm.join()                      # the optimizer (next on the compute stream) waits for the exchange
+            return
+        if self.overlap:
+            self._writes_expected = seen if seen > 0 else None      # learn (first step) or re-learn (fewer writes than expected)
+        for p in self.parameters:
+            p._materialize_zero_grad()            # a lazily zeroed gradient no kernel has written yet (optim.zero_grad)
+        self.comm.allreduce_sum_(self.bucket)
 
     def parameter_digest(self) -> float:
         """sum of |w| over all parameters: equal on every rank iff the replicas are in sync"""

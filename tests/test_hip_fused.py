@@ -254,3 +254,52 @@ def test_lazy_relu_is_folded_into_linear_and_invisible_elsewhere(hip):
         assert np.isnan(got[3]).all()
     r = hip.from_numpy(a[:2]).relu()
     np.testing.assert_allclose(r.sum().item(), np.maximum(a[:2], 0).sum(), rtol=1e-5)
+
+
+def test_lazy_relu_is_a_snapshot_of_its_source(hip):
+    """the reference evaluates relu at once (cpu/ops.py:226); the lazy form must not let a later in-place change of
+    its source show: every writer into existing storage computes the waiting relu first"""
+    rng = np.random.RandomState(23)
+    xn = rng.uniform(-1, 1, (17, 12)).astype(np.float32)
+    for cls in (CpuTensor, hip):
+        np.random.seed(4)
+        l1 = light.nn.Linear(12, 8)
+        if cls is hip:
+            l1.map_parameters(lambda p: p.hip())
+        pre = l1(cls.from_numpy(xn))
+        before = pre.numpy().copy()
+        h = pre.relu()
+        with light.no_grad():
+            pre += 1.0
+        np.testing.assert_array_equal(h.numpy(), np.maximum(before, 0))
+        np.testing.assert_allclose(pre.numpy(), before + 1.0, rtol=1e-6)
+    # every kind of writer: in-place operators, fill, setitem, upload_, optimizer update of a parameter
+    base = rng.uniform(-1, 1, (6, 10)).astype(np.float32)
+    want = np.maximum(base, 0)
+    writers = {
+        "iadd": lambda w: w.__iadd__(1.0), "imul": lambda w: w.__imul__(-2.0), "fill": lambda w: w.fill(-3.0),
+        "setitem": lambda w: w.__setitem__((slice(0, 2), slice(None)), 5.0),
+        "setitem_view": lambda w: w.transpose(1, 0).__setitem__((0, slice(None)), -1.0),
+        "upload": lambda w: w.upload_(np.full((6, 10), -7.0, np.float32)),
+    }
+    for name, write in writers.items():
+        w = hip.from_numpy(base.copy())
+        r = w.relu()
+        assert r.is_lazy()
+        with light.no_grad():
+            write(w)
+        assert not r.is_lazy(), name
+        np.testing.assert_array_equal(r.numpy(), want, err_msg=name)
+    # a parameter: r = w.relu(); optimizer step; r still relu(old w).  Linear folds the lazy relu in forward AND backward
+    np.random.seed(5)
+    l2 = light.nn.Linear(10, 4)
+    l2.map_parameters(lambda p: p.hip())
+    w = hip.from_numpy(base.copy())
+    r = w.relu()
+    loss = light.loss.mse(l2(r), hip.from_numpy(rng.uniform(0, 1, (6, 4)).astype(np.float32), requires_grad=False))
+    loss.backward()
+    opt = light.optim.AdaBelief([w], lr=0.1, fused=True)
+    assert r.is_lazy()
+    opt.step()
+    np.testing.assert_array_equal(r.numpy(), want)
+    assert np.abs(w.numpy() - base).max() > 1e-3

@@ -26,13 +26,16 @@ class HipGraph(object):
 
     def __init__(self):
         self._exec = None
+        self._carried, self._deferred = (), ()      # optimizer step counters the recorded kernels advance (HipTensor._graph_replayed)
 
     @contextmanager
     def capture(self):
         assert self._exec is None, "HipGraph already holds a captured graph"
+        from .tensor import HipTensor
         L = _l.lib()
         _l.check(L.lg_graph_begin())
         HipGraph.capturing = True
+        HipTensor._capture_begins()
         handle = ctypes.c_void_p()
         try:
             yield self
@@ -41,14 +44,25 @@ class HipGraph(object):
             L.lg_graph_end(ctypes.byref(handle))     # leave capture mode, drop whatever was recorded
             if handle.value:
                 L.lg_graph_destroy(handle)
+            HipTensor._capture_ended(ok=False)
             raise
         HipGraph.capturing = False
-        _l.check(L.lg_graph_end(ctypes.byref(handle)))
+        rc = L.lg_graph_end(ctypes.byref(handle))
+        if rc != 0:
+            HipTensor._capture_ended(ok=False)
+            _l.check(rc)
         self._exec = handle
+        import weakref
+        carried, deferred = HipTensor._capture_ended()       # also settles increments owed to the step before the capture
+        self._carried = tuple(weakref.ref(c) for c in carried)
+        self._deferred = tuple(weakref.ref(c) for c in deferred)
 
     def replay(self):
         assert self._exec is not None, "nothing captured"
         _l.check(_l._lib.lg_graph_launch(self._exec))
+        if self._carried or self._deferred:
+            from .tensor import HipTensor
+            HipTensor._graph_replayed(self._carried, self._deferred)
 
     def destroy(self):
         if self._exec is not None and _l._lib is not None:

@@ -85,6 +85,11 @@ PROTOTYPES = {
     "lg_gemm_rowsum_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_int64, c_int, c_void_p, c_int]),
     "lg_mse_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
+    "lg_mse_bump_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "lg_head_fwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_int64, c_int64, c_void_p]),
+    "lg_head_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                c_int64, c_int64, c_int64]),
     "lg_softmax_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
     "lg_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),

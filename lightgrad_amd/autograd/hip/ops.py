@@ -602,18 +602,16 @@ class relu(Function):
         if t.is_contiguous() and t.numel() > 0:
             out = HipTensor(None, t._shape, None, 0, t._dtype)
             out._lazy_source = ("relu", t)
-            # whoever writes into t's storage before `out` has been computed computes it first (flush_lazy_readers)
-            buf = t.data
-            if buf.lazy_readers is None:
-                buf.lazy_readers = []
-            elif len(buf.lazy_readers) >= 64:        # a tensor nobody ever writes (relu of a constant, step after step)
-                buf.lazy_readers = [r for r in buf.lazy_readers if r() is not None and r()._data is None]
-            buf.lazy_readers.append(weakref.ref(out))
+            out._watch_sources(t)      # whoever writes into t's storage before `out` exists computes it first
             return out
         return _unary(_l.EW_RELU, t)
 
     def backward(ctx, out_grad):
         t, = ctx.get_saved_tensors()
+        done = out_grad._relu_bwd_done
+        if done is not None and done[0] is t:
+            # the kernel that made this gradient (head_bwd) already wrote `out_grad * (t >= 0)` next to it
+            return done[1]
         return _binary(_l.EW_RELU_BWD, t, out_grad)
 
 
@@ -866,6 +864,13 @@ class linear(Function):
     def forward(ctx, x, weight, bias=None):
         ctx.save_for_backward(x, weight, bias is not None)
         pre = _lazy_relu_input(x)
+        src = pre if pre is not None else x
+        if _head_eligible(src, weight, bias):
+            # a skinny output layer: wait and see whether the loss wants it - loss.mse then computes both in one launch
+            out = HipTensor(None, (src._shape[0], weight._shape[0]), None, 0, _F32)
+            out._lazy_source = ("head", src, pre is not None, weight, bias)
+            out._watch_sources(src, weight, bias)
+            return out
         if pre is not None and x._shape[0] > 0:
             # x = relu(pre) that nobody has looked at yet: the GEMM reads pre and applies the relu while staging it
             return _gemm_fused(pre, _swap_last(weight), bias=bias, relu_a=True)[0]
@@ -879,6 +884,8 @@ class linear(Function):
         pre = _lazy_relu_input(x) if g2._shape[0] > 0 else None
         if pre is not None:
             return linear._backward_through_lazy_relu(x, pre, weight, bias, g2)
+        if (weight.requires_grad and x.requires_grad and len(x._shape) == 2 and _head_eligible(x, weight, bias) and g2.is_contiguous()):
+            return _head_backward(x, x, False, weight, bias, g2)
         x2 = x.reshape(-1, x._shape[-1])
         # leaf operands that already own a gradient buffer (parameters after zero_grad, a re-used input) get their
         # gradient ADDED in place by the producing kernel (GEMM with beta = 1 / reduction with accumulate) and None
@@ -932,6 +939,8 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
     factor is relu.backward's job).  Same values as with a materialised x."""
     dw = dx = db = None
     want_db = bias is not None and bias.requires_grad
+    if weight.requires_grad and _head_eligible(pre, weight, bias) and g2.is_contiguous():
+        return _head_backward(x, pre, True, weight, bias, g2)
     if weight.requires_grad:
         acc_w = weight._grad_accumulator()
         acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
@@ -964,6 +973,73 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
 
 
 linear._backward_through_lazy_relu = staticmethod(_linear_backward_through_lazy_relu)
+
+
+def _head_eligible(x, weight, bias) -> bool:
+    """a Linear small enough for csrc/head.hip: dense 2-D fp32 input (or pre-activation), <= 16 output features, the
+    alignment its float4 loads need and a weight matrix that fits the 64 KiB LDS stage"""
+    if len(x._shape) != 2 or len(weight._shape) != 2 or x._dtype != _F32 or weight._dtype != _F32:
+        return False
+    rows, hidden = x._shape
+    outs = weight._shape[0]
+    if rows < 1 or not 1 <= outs <= 16 or hidden < 4 or hidden % 4 or outs * hidden * 4 > 65536 or weight._shape[1] != hidden:
+        return False
+    if not (x.is_contiguous() and weight.is_contiguous()) or (bias is not None and not (bias.is_contiguous() and bias._dtype == _F32)):
+        return False
+    return x.ptr % 16 == 0 and weight.ptr % 16 == 0
+
+
+def head_mse_forward(y, y_hat):
+    """loss.mse of a still-lazy skinny output layer `y`: (loss, err) AND y itself from one launch (lg_head_fwd_f32).
+    Returns None when the fused form does not apply (the caller then materialises y the plain way)."""
+    _, x, relu, weight, bias = y._lazy_source
+    if not isinstance(y_hat, HipTensor) or y_hat._shape != y._shape or y_hat._dtype != _F32 or not _head_eligible(x, weight, bias):
+        return None
+    y_hat = y_hat.contiguous()
+    rows, hidden = x._shape
+    outs = weight._shape[0]
+    out, err, loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty(())
+    counter = HipTensor._take_deferred_step_advance()
+    _l.check(_l.lib().lg_head_fwd_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
+                                      out.ptr, err.ptr, loss.ptr, rows, hidden, outs, counter.ptr if counter is not None else None))
+    y._data, y._offset, y._lazy_source = out._data, out._offset, None           # y is real now
+    return loss, err
+
+
+def _head_backward(x, src, relu, weight, bias, g2):
+    """linear.backward of a skinny output layer in ONE launch (lg_head_bwd_f32): dx, dW, db - and, when the layer's
+    input is a lazy relu(src), that relu's backward result too, handed to relu.backward through `_relu_bwd_done`."""
+    rows, hidden = src._shape
+    outs = weight._shape[0]
+    want_db = bias is not None and bias.requires_grad
+    acc_w = weight._grad_accumulator()
+    acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+    acc_b = bias._grad_accumulator() if want_db else None
+    acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+    for t in (acc_w, acc_b):
+        if t is not None:
+            flush_lazy_readers(t)
+    dw = acc_w if acc_w is not None else HipTensor.empty(weight._shape)
+    db = (acc_b if acc_b is not None else HipTensor.empty((outs,))) if want_db else None
+    dx = HipTensor.empty((rows, hidden)) if x.requires_grad else None
+    gpre = HipTensor.empty((rows, hidden)) if (relu and dx is not None) else None
+    _l.check(_l.lib().lg_head_bwd_f32(
+        src.ptr, hidden, 1 if relu else 0, g2.ptr, weight.ptr,
+        dx.ptr if dx is not None else None, gpre.ptr if gpre is not None else None,
+        dw.ptr, 1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
+        db.ptr if db is not None else None, 1 if (acc_b is not None and not bias._consume_zero_pending()) else 0,
+        rows, hidden, outs))
+    if acc_w is not None:
+        weight._notify_grad_written()
+    if acc_b is not None:
+        bias._notify_grad_written()
+    if gpre is not None:
+        dx._relu_bwd_done = (src, gpre)
+    if dx is not None and len(x._shape) != 2:
+        dx = dx.reshape(*x._shape)
+    if bias is None:
+        return dx, (None if acc_w is not None else dw)
+    return dx, (None if acc_w is not None else dw), (None if (acc_b is not None or db is None) else db)
 
 
 gelu = HipTensor.register_op("gelu", _unary_op("gelu", _l.EW_GELU, _l.EW_GELU_BWD, False,
@@ -1087,7 +1163,8 @@ def mse_forward(y, y_hat):
     assert y._shape == y_hat._shape, "mse: shapes %s and %s differ" % (y._shape, y_hat._shape)
     y, y_hat = y.contiguous(), y_hat.contiguous()
     err, loss = HipTensor.empty(y._shape), HipTensor.empty(())
-    _l.check(_l.lib().lg_mse_f32(y.ptr, y_hat.ptr, err.ptr, loss.ptr, y.numel()))
+    counter = HipTensor._take_deferred_step_advance()       # an optimizer's step counter rides along (tensor.py)
+    _l.check(_l.lib().lg_mse_bump_f32(y.ptr, y_hat.ptr, err.ptr, loss.ptr, y.numel(), counter.ptr if counter is not None else None))
     return loss, err
 
 

@@ -157,11 +157,20 @@ class HipTensor(AbstractTensor):
     def offset(self) -> int:
         return self._offset
 
-    # A LAZY tensor has no buffer yet: `_lazy_source` = (kind, input tensor) says how to make it ("relu" only).  It is
-    # created by relu.forward; a consumer that can fold the relu into its own kernel (linear) reads the input instead and
-    # the relu never runs.  Anything else that asks for `data` / `ptr` runs it first - so a lazy tensor behaves like
-    # any other everywhere, it just costs nothing until someone looks.
+    # A LAZY tensor has no buffer yet: `_lazy_source` says how to make it.
+    #   ("relu", t)                      created by relu.forward; a consumer that can fold the relu into its own kernel
+    #                                    (linear, the head kernels) reads t instead and the relu never runs
+    #   ("head", x, relu, weight, bias)  created by linear.forward for a skinny output layer (<= 16 features):
+    #                                    act(x) @ weight^T + bias, act = relu if `relu` else identity; loss.mse computes
+    #                                    it together with the loss in one launch (csrc/head.hip)
+    # Anything else that asks for `data` / `ptr` runs the plain kernel first - so a lazy tensor behaves like any other
+    # everywhere, it just costs nothing until someone looks.  In-place writers into the sources' storage compute the
+    # waiting tensor first (flush_lazy_readers), so it is a snapshot like the reference's eager result.
     _lazy_source = None
+
+    # set on a gradient tensor by the kernel that produced it when the same launch already wrote relu.backward's result
+    # for it: (t, out_grad * (t >= 0)) - relu.backward of exactly that t then returns the second tensor without a launch
+    _relu_bwd_done = None
 
     @property
     def data(self):
@@ -173,12 +182,34 @@ class HipTensor(AbstractTensor):
         return self._data is None
 
     def _materialize(self) -> None:
-        kind, src = self._lazy_source
-        assert kind == "relu"
         from . import ops as _ops
-        out = HipTensor.empty(self._shape, requires_grad=False)
-        _ops._ew(_l.EW_RELU, self._shape, [src], out=out)
+        kind = self._lazy_source[0]
+        if kind == "relu":
+            src = self._lazy_source[1]
+            out = HipTensor.empty(self._shape, requires_grad=False)
+            _ops._ew(_l.EW_RELU, self._shape, [src], out=out)
+        else:
+            assert kind == "head"
+            _, x, relu, weight, bias = self._lazy_source
+            if relu:
+                out = _ops._gemm_fused(x, _ops._swap_last(weight), bias=bias, relu_a=True)[0]
+            else:
+                out = _ops._gemm(x, _ops._swap_last(weight), bias=bias)
         self._data, self._offset, self._lazy_source = out._data, out._offset, None
+
+    def _watch_sources(self, *sources) -> None:
+        """register this lazy tensor with the storage of everything it will read (see flush_lazy_readers)"""
+        import weakref
+        ref = weakref.ref(self)
+        for t in sources:
+            if t is None:
+                continue
+            buf = t.data
+            if buf.lazy_readers is None:
+                buf.lazy_readers = []
+            elif len(buf.lazy_readers) >= 64:        # storage nobody ever writes (relu of a constant, step after step)
+                buf.lazy_readers = [r for r in buf.lazy_readers if r() is not None and r()._data is None]
+            buf.lazy_readers.append(ref)
 
     @property
     def ptr(self) -> int:
@@ -367,8 +398,13 @@ class HipTensor(AbstractTensor):
         adam_step_(self, grad, m, v, lr, b1, b2, eps, inv_bias1, inv_bias2, grad_scale, belief)
 
     def _fused_mse(self, y_hat):
-        """optional loss hook (loss.mse): (loss, err) from one kernel instead of seven tape ops"""
-        from .ops import mse_forward
+        """optional loss hook (loss.mse): (loss, err) from one kernel instead of seven tape ops; a still-lazy skinny
+        output layer is computed in the same launch (csrc/head.hip)"""
+        from .ops import mse_forward, head_mse_forward
+        if self._data is None and self._lazy_source is not None and self._lazy_source[0] == "head":
+            fused = head_mse_forward(self, y_hat)
+            if fused is not None:
+                return fused
         return mse_forward(self, y_hat)
 
     def _fused_cross_entropy(self, labels):
@@ -382,11 +418,13 @@ class HipTensor(AbstractTensor):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         assert offsets[-1] == self.numel()
         flush_lazy_readers(self)
+        self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
                                                 lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 0))
         # advance = 0: the ticket form (the last working workgroup increments the counter) costs one contended atomic per
-        # working workgroup - measured 2 % slower per MLP step (~400 tickets) than the separate 1-thread launch below
-        self._advance_step_counter(step_counter)
+        # working workgroup - measured 2 % slower per MLP step (~400 tickets) than a separate 1-thread launch.  Cheaper
+        # than both: the NEXT step's loss kernel carries the increment (see _advance_step_counter)
+        self._advance_step_counter(step_counter, defer=True)
 
     @staticmethod
     def _new_step_counter(step: int) -> "HipTensor":
@@ -398,12 +436,108 @@ class HipTensor(AbstractTensor):
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         flush_lazy_readers(self)
+        self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_adam_step_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, self.numel(), lr, b1, b2, eps,
                                                step_counter.ptr, t_mul, t_add, grad_scale, 1 if belief else 0))
 
+    # Device step counters whose "+1" has not been enqueued yet.  An optimizer step ends by advancing its counter; that
+    # increment only has to land before the optimizer's NEXT kernel reads the counter, so instead of a 1-thread launch of
+    # its own (4 us of a 100 us training step) it waits here for a kernel that runs exactly once per training step anyway:
+    # the fused loss of the next forward pass (lg_head_fwd_f32 / lg_mse_bump_f32 take the counter as an argument).  If no
+    # such kernel came by, the optimizer flushes the increment itself before it reads the counter again.
+    #
+    # hipGraph capture (autograd/hip/graph.py calls _capture_begins / _capture_ended / _graph_replayed): a capture pass
+    # executes nothing, so the list is restored when it ends, and what the recorded kernels do to it is replayed with them:
+    #   * a loss kernel recorded in the capture carried the waiting increment -> an optimizer recorded after it defers again
+    #     (warm capture of a whole training step: the graph holds exactly one increment and no launch for it); every
+    #     replay takes one waiting entry and adds one
+    #   * nothing carried it -> the optimizer records its own 1-thread increment in the graph, as it would eagerly
+    #   * an increment of the step BEFORE the capture that no recorded kernel carried is executed once, when the capture
+    #     has ended (it belongs to that step, not to every replay)
+    _deferred_step_advances = []          # weak references: a counter dies with its optimizer
+    _capture_state = None                 # during a capture: {"snapshot", "carried", "deferred", "owed"}
+
     @staticmethod
-    def _advance_step_counter(step_counter, delta: int = 1) -> None:
+    def _waiting_step_counters():
+        """the live counters with an increment waiting, oldest first (entries of dead optimizers are dropped)"""
+        alive = [(r, r()) for r in HipTensor._deferred_step_advances]
+        HipTensor._deferred_step_advances[:] = [r for r, c in alive if c is not None]
+        return [c for _, c in alive if c is not None]
+
+    @staticmethod
+    def _drop_waiting(step_counter) -> bool:
+        pending = HipTensor._deferred_step_advances
+        for i, ref in enumerate(pending):
+            if ref() is step_counter:
+                del pending[i]
+                return True
+        return False
+
+    @staticmethod
+    def _advance_step_counter(step_counter, delta: int = 1, defer: bool = False) -> None:
+        if defer and delta == 1:
+            import weakref
+            cap = HipTensor._capture_state
+            if cap is None:
+                HipTensor._deferred_step_advances.append(weakref.ref(step_counter))
+                return
+            if any(c is step_counter for c in cap["carried"]):
+                cap["deferred"].append(step_counter)
+                return
         _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, delta))
+
+    @staticmethod
+    def _flush_step_counter(step_counter) -> None:
+        """the optimizer is about to read `step_counter`: enqueue an increment that is still waiting for a carrier"""
+        if HipTensor._drop_waiting(step_counter):
+            cap = HipTensor._capture_state
+            if cap is not None:
+                cap["owed"].append(step_counter)          # belongs to the step before the capture: executed once, afterwards
+            else:
+                _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, 1))
+
+    @staticmethod
+    def _take_deferred_step_advance():
+        """for a loss kernel of a TRAINING forward pass: the counter it should increment, or None"""
+        from ..grads import Gradients
+        # depth 1 = inside a first-class op's forward with gradients otherwise enabled; deeper = the user's no_grad()
+        if HipTensor._deferred_step_advances and Gradients._disable_depth == 1:
+            waiting = HipTensor._waiting_step_counters()
+            if waiting:
+                del HipTensor._deferred_step_advances[0]
+                if HipTensor._capture_state is not None:
+                    HipTensor._capture_state["carried"].append(waiting[0])
+                return waiting[0]
+        return None
+
+    @staticmethod
+    def _capture_begins() -> None:
+        HipTensor._capture_state = {"snapshot": list(HipTensor._deferred_step_advances), "carried": [], "deferred": [], "owed": []}
+
+    @staticmethod
+    def _capture_ended(ok: bool = True):
+        """restore the waiting list (the capture pass executed nothing), settle what is owed to the step before the
+        capture, and hand the graph what its recorded kernels do per replay: (counters carried, counters deferred)"""
+        cap, HipTensor._capture_state = HipTensor._capture_state, None
+        HipTensor._deferred_step_advances[:] = cap["snapshot"]
+        if not ok:
+            return [], []
+        for counter in cap["owed"]:
+            HipTensor._drop_waiting(counter)
+            _l.check(_l.lib().lg_counter_add_i64(counter.ptr, 1))
+        return cap["carried"], cap["deferred"]
+
+    @staticmethod
+    def _graph_replayed(carried, deferred) -> None:
+        import weakref
+        for ref in carried:
+            c = ref()
+            if c is not None:
+                HipTensor._drop_waiting(c)
+        for ref in deferred:
+            c = ref()
+            if c is not None:
+                HipTensor._deferred_step_advances.append(weakref.ref(c))
 
     def __repr__(self):
         return "HipTensor(shape=%s, strides=%s, dtype=%s)" % (self._shape, self._strides, self._dtype)

@@ -126,7 +126,7 @@ class Adam(Optimizer):
                 kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
                        (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
         if self._step_counter is not None:
-            self.parameters[0]._advance_step_counter(self._step_counter)
+            self.parameters[0]._advance_step_counter(self._step_counter, defer=True)
 
     def on_graph_replay(self, n: int = 1) -> None:
         """keep the host-side step count in line after `n` replays of a captured step"""

@@ -1,0 +1,310 @@
+"""csrc/head.hip - the skinny output layer + loss in two launches - against numpy (float64) through the raw C ABI,
+against the unfused tape on the CPU backend (itself pinned to the reference's fixtures), and the optimizer step
+counter that rides along in the loss kernel."""
+import ctypes
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from lightgrad_amd import CpuTensor
+from test_cpu_backend import MLP
+
+pytestmark = pytest.mark.gpu
+
+
+def _relu(a):
+    with np.errstate(invalid="ignore"):
+        return np.maximum(a, 0)
+
+
+@pytest.mark.parametrize("rows,hidden,outs,relu,with_bias", [
+    (1024, 512, 10, 1, True),          # the MNIST head
+    (1, 4, 1, 0, False), (3, 8, 2, 1, True), (65, 36, 7, 1, True), (130, 100, 16, 0, True), (257, 1024, 16, 1, False),
+    (4100, 64, 10, 1, True),           # more rows than the grid has waves: the row loop
+])
+def test_head_forward_c_abi(hip, rows, hidden, outs, relu, with_bias):
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(rows + hidden + outs)
+    x = rng.uniform(-1, 1, (rows, hidden)).astype(np.float32)
+    x[0, 0] = 0.0
+    w = (rng.uniform(-1, 1, (outs, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    b = rng.uniform(-1, 1, (outs,)).astype(np.float32)
+    t = rng.uniform(0, 1, (rows, outs)).astype(np.float32)
+    tx, tw, tb, tt = (hip.from_numpy(a, requires_grad=False) for a in (x, w, b, t))
+    y, err, loss = hip.empty((rows, outs)), hip.empty((rows, outs)), hip.empty(())
+    counter = hip.from_numpy(np.asarray([41, 0], np.int64), requires_grad=False)
+    for use_counter in (False, True):
+        L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, relu, tw.ptr, tb.ptr if with_bias else None, tt.ptr, y.ptr, err.ptr, loss.ptr,
+                                    rows, hidden, outs, counter.ptr if use_counter else None))
+    a64 = (_relu(x) if relu else x).astype(np.float64)
+    y_ref = a64 @ w.astype(np.float64).T + (b if with_bias else 0)
+    e_ref = y_ref - t
+    np.testing.assert_allclose(y.numpy(), y_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(err.numpy(), e_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(loss.item(), (e_ref ** 2).mean() / 2, rtol=1e-5)
+    np.testing.assert_array_equal(counter.numpy(), [42, 0])             # advanced exactly once, by the launch that was given it
+    # err is exactly y + (-target) of the y that was written (one rounding, like the tape's `y - y_hat`)
+    np.testing.assert_array_equal(err.numpy(), y.numpy() + (-t))
+    # bit-reproducible from launch to launch
+    first = (y.numpy().copy(), loss.numpy().copy())
+    L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, relu, tw.ptr, tb.ptr if with_bias else None, tt.ptr, y.ptr, err.ptr, loss.ptr,
+                                rows, hidden, outs, None))
+    np.testing.assert_array_equal(y.numpy(), first[0])
+    np.testing.assert_array_equal(loss.numpy(), first[1])
+
+
+@pytest.mark.parametrize("rows,hidden,outs,relu", [
+    (1024, 512, 10, 1), (1, 4, 1, 0), (3, 8, 2, 1), (65, 36, 7, 1), (130, 100, 16, 0), (700, 1000, 3, 1), (5000, 40, 10, 1),
+])
+def test_head_backward_c_abi(hip, rows, hidden, outs, relu):
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(7 * rows + hidden + outs)
+    x = rng.uniform(-1, 1, (rows, hidden)).astype(np.float32)
+    x[0, 0] = 0.0                                                        # relu.backward passes the gradient at exactly 0
+    if hidden > 1:
+        x[0, 1] = -0.0
+    g = rng.uniform(-1, 1, (rows, outs)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (outs, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    tx, tg, tw = (hip.from_numpy(a, requires_grad=False) for a in (x, g, w))
+    dx, gpre = hip.empty((rows, hidden)), hip.empty((rows, hidden))
+    dw0 = rng.uniform(-1, 1, (outs, hidden)).astype(np.float32)
+    db0 = rng.uniform(-1, 1, (outs,)).astype(np.float32)
+    g64, w64 = g.astype(np.float64), w.astype(np.float64)
+    a64 = (_relu(x) if relu else x).astype(np.float64)
+    dx_ref, dw_ref, db_ref = g64 @ w64, g64.T @ a64, g64.sum(axis=0)
+    scale = np.abs(g64).T @ np.abs(a64) + 1e-30                          # what rounding errors are relative to
+    for accumulate in (0, 1):
+        dw, db = hip.from_numpy(dw0.copy(), requires_grad=False), hip.from_numpy(db0.copy(), requires_grad=False)
+        L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, relu, tg.ptr, tw.ptr, dx.ptr, gpre.ptr if relu else None,
+                                    dw.ptr, accumulate, db.ptr, accumulate, rows, hidden, outs))
+        np.testing.assert_allclose(dx.numpy(), dx_ref, rtol=1e-5, atol=1e-6)
+        if relu:
+            np.testing.assert_array_equal(gpre.numpy(), dx.numpy() * (x >= 0))           # relu.backward: g * (t >= 0)
+        got_dw = dw.numpy().astype(np.float64) - (dw0 if accumulate else 0)
+        assert np.max(np.abs(got_dw - dw_ref) / scale) < 2e-6
+        np.testing.assert_allclose(db.numpy().astype(np.float64) - (db0 if accumulate else 0), db_ref, rtol=1e-5, atol=1e-5 * max(1, rows / 64))
+    # optional outputs: dW only / dx only; and bit-reproducibility
+    dw_a, dw_b = hip.empty((outs, hidden)), hip.empty((outs, hidden))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, relu, tg.ptr, tw.ptr, None, None, dw_a.ptr, 0, None, 0, rows, hidden, outs))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, relu, tg.ptr, tw.ptr, dx.ptr, None, dw_b.ptr, 0, None, 0, rows, hidden, outs))
+    np.testing.assert_array_equal(dw_a.numpy(), dw_b.numpy())
+    dx_only = hip.empty((rows, hidden))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, relu, tg.ptr, tw.ptr, dx_only.ptr, None, None, 0, None, 0, rows, hidden, outs))
+    np.testing.assert_array_equal(dx_only.numpy(), dx.numpy())
+
+
+def test_head_c_abi_rejects_what_it_cannot_do(hip):
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    t = hip.zeros((8, 8), requires_grad=False)
+    assert lib.lg_head_fwd_f32(t.ptr, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 8, 17, None) != 0          # > 16 outputs
+    assert b"outs" in lib.lg_last_error()
+    assert lib.lg_head_fwd_f32(t.ptr, 6, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 6, 4, None) != 0           # hidden % 4
+    assert lib.lg_head_fwd_f32(t.ptr + 4, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 7, 8, 4, None) != 0       # misaligned x
+    assert lib.lg_head_bwd_f32(t.ptr, 8, 0, t.ptr, t.ptr, t.ptr, t.ptr, None, 0, None, 0, 8, 8, 4) != 0            # gpre without relu
+    assert lib.lg_head_bwd_f32(None, 8, 0, t.ptr, t.ptr, None, None, None, 0, None, 0, 8, 8, 4) != 0
+
+
+@pytest.mark.parametrize("d_in,d_hid,d_out,batch", [(20, 16, 7, 33), (784, 512, 10, 1024), (12, 8, 16, 5), (30, 24, 1, 64)])
+def test_tape_with_fused_head_equals_cpu_backend(hip, d_in, d_hid, d_out, batch):
+    """Linear -> relu -> Linear(<= 16) -> mse: the tape must hand out the same values, ALL gradients included (the lazy relu
+    output's own, which is dx WITHOUT the relu mask), as the unfused CPU backend; 3 launches carry forward head + loss,
+    backward head, nothing else"""
+    rng = np.random.RandomState(d_in + d_out)
+    xn = rng.uniform(-1, 1, (batch, d_in)).astype(np.float32)
+    tn = rng.uniform(0, 1, (batch, d_out)).astype(np.float32)
+    res = {}
+    for cls in (CpuTensor, hip):
+        np.random.seed(11)
+        model = MLP(d_in, d_hid, d_out)
+        if cls is hip:
+            model.map_parameters(lambda p: p.hip())
+        x = cls.from_numpy(xn)
+        pre = model.l1(x)
+        h = pre.relu()
+        y = model.l2(h)
+        if cls is hip:
+            assert y.is_lazy() and h.is_lazy()
+        loss = light.loss.mse(y, cls.from_numpy(tn, requires_grad=False))
+        if cls is hip:
+            assert not y.is_lazy() and h.is_lazy()                       # the loss made y real in its own launch
+        loss.backward()
+        if cls is hip:
+            assert h.is_lazy()
+        res[cls] = [loss.numpy(), y.numpy(), y.grad.numpy(), h.grad.numpy(), pre.grad.numpy(), x.grad.numpy()] + \
+                   [p.grad.numpy() for p in model.parameters()]
+    for got, ref in zip(res[hip], res[CpuTensor]):
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_lazy_head_behaves_like_a_tensor_everywhere_else(hip):
+    """a skinny Linear whose output is NOT fed to mse is computed by the plain kernel when somebody looks, snapshots its
+    sources, and a second gradient contribution to the relu output bypasses the relu shortcut"""
+    rng = np.random.RandomState(3)
+    xn = rng.uniform(-1, 1, (9, 12)).astype(np.float32)
+    np.random.seed(2)
+    lin = light.nn.Linear(12, 4)
+    w, b = lin.weight.numpy().copy(), lin.bias.numpy().copy()
+    lin.map_parameters(lambda p: p.hip())
+    x = hip.from_numpy(xn)
+    y = lin(x)
+    assert y.is_lazy()
+    with light.no_grad():
+        x += 1.0                                                         # y was defined from the OLD x
+    np.testing.assert_allclose(y.numpy(), xn.astype(np.float64) @ w.T + b, rtol=1e-5, atol=1e-6)
+    y2 = lin(x.relu())
+    with light.no_grad():
+        lin.weight.fill(0.0)                                             # ... and from the OLD weights
+    np.testing.assert_allclose(y2.numpy(), _relu(xn + 1.0).astype(np.float64) @ w.T + b, rtol=1e-5, atol=1e-6)
+    # elementwise / reduction / cross-entropy consumers of a lazy head
+    lin2 = light.nn.Linear(12, 5)
+    w2, b2 = lin2.weight.numpy().copy(), lin2.bias.numpy().copy()
+    lin2.map_parameters(lambda p: p.hip())
+    z = lin2(hip.from_numpy(xn))
+    ref = xn.astype(np.float64) @ w2.T + b2
+    np.testing.assert_allclose((z * 2.0).numpy(), 2 * ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lin2(hip.from_numpy(xn)).sum().numpy(), ref.sum(), rtol=1e-5)
+    labels = rng.randint(0, 5, 9).astype(np.int64)
+    ce = light.loss.cross_entropy(lin2(hip.from_numpy(xn)), hip.from_numpy(labels, requires_grad=False))
+    p = np.exp(ref - ref.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    np.testing.assert_allclose(ce.item(), -np.log(p[np.arange(9), labels]).mean(), rtol=1e-5)
+    # relu output used twice: its gradient is a sum, so relu.backward must run its own kernel
+    res = {}
+    for cls in (CpuTensor, hip):
+        np.random.seed(5)
+        l1, l2 = light.nn.Linear(12, 8), light.nn.Linear(8, 3)
+        if cls is hip:
+            l1.map_parameters(lambda p: p.hip())
+            l2.map_parameters(lambda p: p.hip())
+        xx = cls.from_numpy(xn)
+        pre = l1(xx)
+        h = pre.relu()
+        out = l2(h)
+        loss = light.loss.mse(out, cls.zeros((9, 3), requires_grad=False)) + (h * h).sum() * 0.01
+        loss.backward()
+        res[cls] = [loss.numpy(), pre.grad.numpy(), xx.grad.numpy()] + [q.grad.numpy() for q in list(l1.parameters()) + list(l2.parameters())]
+    for got, ref in zip(res[hip], res[CpuTensor]):
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("loss_kind", ["head", "plain_mse", "other"])
+def test_step_counter_rides_in_the_loss_kernel(hip, loss_kind):
+    """device_step optimizers: the increment of the step counter is carried by the next training step's fused loss (no
+    launch of its own); a forward pass under no_grad must not carry it, and without a carrier the optimizer flushes it.
+    Pinned by equality with the host-scalar optimizer, whose bias corrections depend on the step number."""
+    from lightgrad_amd.autograd.hip import HipTensor
+    rng = np.random.RandomState(0)
+    xn = rng.uniform(0, 1, (16, 12)).astype(np.float32)
+    tn = rng.uniform(0, 1, (16, 4)).astype(np.float32)
+    finals = []
+    import gc
+    gc.collect()                                                         # optimizers of earlier tests are gone
+    for device_step in (False, True):
+        np.random.seed(1)
+        model = MLP(12, 8, 4).map_parameters(lambda p: p.hip())
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-2, fused=True, device_step=device_step)
+        x, t = hip.from_numpy(xn), hip.from_numpy(tn, requires_grad=False)
+        for step in range(4):
+            y = model(x)
+            if loss_kind == "head":
+                loss = light.loss.mse(y, t)
+            elif loss_kind == "plain_mse":
+                loss = light.loss.mse(y * 1.0, t)                        # y is materialised by the multiplication: lg_mse_bump_f32
+            else:
+                loss = ((y - t) ** 2).mean()                             # no fused loss at all: the optimizer flushes
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if device_step:
+                assert len(HipTensor._waiting_step_counters()) == 1
+                with light.no_grad():
+                    light.loss.mse(model(x), t)                          # evaluation pass: must not advance anything
+                assert len(HipTensor._waiting_step_counters()) == 1
+                c = opt._step_counter.numpy()[0]
+                assert c == step, (c, step)                              # the "+1" of this step is still waiting
+        finals.append([p.numpy() for p in model.parameters()])
+        if device_step:
+            HipTensor._flush_step_counter(opt._step_counter)
+            assert opt._step_counter.numpy()[0] == 4 and not HipTensor._waiting_step_counters()
+    for a, b in zip(*finals):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("scenario", ["warm_whole_step", "nothing_waiting_at_capture", "no_carrier_in_graph", "graph_fwd_bwd_eager_optimizer",
+                                      "capture_then_eager"])
+def test_step_counter_stays_right_across_graph_capture(hip, scenario):
+    """one increment of the device step counter per training step, whatever mix of eager steps, captures and replays:
+    the weights after 7 steps must equal those of the host-scalar optimizer (its bias corrections depend on the step)"""
+    from lightgrad_amd.autograd.hip import HipGraph, HipTensor
+    import gc
+    gc.collect()
+    rng = np.random.RandomState(0)
+    xn = rng.uniform(0, 1, (16, 12)).astype(np.float32)
+    tn = rng.uniform(0, 1, (16, 4)).astype(np.float32)
+    total = 7
+
+    def build(device_step):
+        np.random.seed(1)
+        model = MLP(12, 8, 4).map_parameters(lambda p: p.hip())
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-2, fused=True, device_step=device_step)
+        x, t = hip.from_numpy(xn), hip.from_numpy(tn, requires_grad=False)
+
+        def fwd_bwd():
+            y = model(x)
+            loss = ((y - t) ** 2).mean() if scenario == "no_carrier_in_graph" else light.loss.mse(y, t)
+            opt.zero_grad()
+            loss.backward()
+            return loss
+
+        def step():
+            loss = fwd_bwd()
+            opt.step()
+            return loss
+        return model, opt, fwd_bwd, step
+
+    model, opt, _, step = build(False)
+    for _ in range(total):
+        step()
+    want = [p.numpy() for p in model.parameters()]
+
+    model, opt, fwd_bwd, step = build(True)
+    n_params = len(opt.parameters)
+    if scenario == "nothing_waiting_at_capture":
+        done = 0
+    else:
+        for _ in range(2):
+            step()
+        done = 2
+    g = HipGraph()
+    if scenario == "graph_fwd_bwd_eager_optimizer":
+        with g.capture():
+            fwd_bwd()
+        while done < total:
+            g.replay()
+            opt.step()
+            done += 1
+    elif scenario == "capture_then_eager":
+        with g.capture():
+            step()
+        opt.t -= n_params
+        g.replay()
+        opt.on_graph_replay()
+        done += 1
+        while done < total:                                              # back to the python tape after a replay
+            step()
+            done += 1
+    else:
+        with g.capture():
+            step()
+        opt.t -= n_params
+        while done < total:
+            g.replay()
+            opt.on_graph_replay()
+            done += 1
+    HipTensor._flush_step_counter(opt._step_counter)
+    assert opt._step_counter.numpy()[0] == total
+    for a, b in zip([p.numpy() for p in model.parameters()], want):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+    g.destroy()

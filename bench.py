@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--comm-dispatch", choices=["graph", "eager"], default="graph",
                     help="N > 1: graph = the all-reduce is a forked branch INSIDE the captured step (no host call per step); "
                          "eager = forward+backward replay from a graph, all-reduce and optimizer are host calls")
+    ap.add_argument("--graph-steps", type=int, default=8,
+                    help="training steps recorded per hipGraph (each one complete: forward, backward, exchange, update); a replay "
+                         "boundary costs ~8 us of idle GPU, so several steps per graph amortise it.  1 = one step per replay")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the GPU work (launcher / protocol test)")
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before the self-launcher gives up")
     return ap.parse_args()
@@ -242,9 +245,11 @@ def gpu_rank(args, rank, world):
 
     step = eager_step
     comm_in_graph = False
+    unroll = 1
+    # three eager steps first: they allocate optimizer state, fill the pool, load kernels and teach DataParallel(overlap=True)
+    # where the last gradient write is - and their losses are the parity check against the CPU backend on the same problem
+    first_losses = [eager_step().item() for _ in range(3)]
     if use_graph:
-        for _ in range(3):                       # eager: allocates optimizer state, fills the pool, loads kernels, and
-            eager_step()                         # teaches DataParallel(overlap=True) where the last gradient write is
         n_params = len(opt.parameters)
         g_all = None
         if not multi or args.comm_dispatch == "graph":
@@ -267,6 +272,18 @@ def gpu_rank(args, rank, world):
                 g_all.replay()
                 opt.on_graph_replay()
                 return graph_loss
+            # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
+            # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
+            # on the resident batch; the timed loop below still performs exactly --steps of them.
+            unroll = max(1, min(args.graph_steps, args.steps))
+            while args.steps % unroll:
+                unroll -= 1
+            if unroll > 1:
+                g_multi = HipGraph()
+                with g_multi.capture():
+                    for _ in range(unroll):
+                        multi_loss = eager_step()
+                opt.t -= unroll * n_params
         else:
             # fallback (--comm-dispatch eager): forward+backward replay from a graph; the RCCL all-reduce and the optimizer
             # launch follow as host calls on the same stream
@@ -282,10 +299,19 @@ def gpu_rank(args, rank, world):
 
     for _ in range(args.warmup):
         loss = step()
+    if unroll > 1:
+        g_multi.replay()                             # untimed: first launch of the multi-step graph
+        opt.on_graph_replay(unroll)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    if unroll > 1:
+        for _ in range(args.steps // unroll):
+            g_multi.replay()
+            opt.on_graph_replay(unroll)
+        loss = multi_loss
+    else:
+        for _ in range(args.steps):
+            loss = step()
     fence()
     mine = time.perf_counter() - t0
     elapsed = wall_max(mine)
@@ -357,16 +383,18 @@ def gpu_rank(args, rank, world):
                    "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
                    "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
                    "input_requires_grad": True,
-                   "dispatch": "hipGraph replay (python tape captured once)" if use_graph else "eager python tape",
+                   "dispatch": ("hipGraph replay (python tape captured once; %d consecutive steps per graph)" % unroll) if use_graph else "eager python tape",
+                   "steps_per_graph": unroll,
                    "device": info["name"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
         "final_loss": round(final_loss, 6),
+        "first_losses": [round(v, 7) for v in first_losses],
         "ranks": ranks_info,
         "mlp_gemm_tflops": round(steps_per_s * MLP_GEMM_FLOP / 1e12, 3),
         "mlp_steps_per_sec_eager": round(eager_steps_per_s, 2),
         "mlp_steps_per_sec_batch_as_data": None if data_input_steps_per_s is None else round(data_input_steps_per_s, 2),
     }
     if not args.no_extras:
-        out.update(extras(args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel,
+        out.update(extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel,
                           SingleProcess, wall_max, fence, under_profiler, w0, x_np, onehot_np))
     if multi:
         comm.close()
@@ -374,7 +402,7 @@ def gpu_rank(args, rank, world):
         print(json.dumps(out))
 
 
-def extras(args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel, SingleProcess,
+def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel, SingleProcess,
            wall_max, fence, under_profiler, w0, x_np, onehot_np):
     """everything besides the headline: 4096^2 matmul, roofline of the dominant kernel, HBM microbench, tiny-BERT, CPU baseline"""
     import ctypes
@@ -541,6 +569,9 @@ def extras(args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b)
+        cpu_first = cpu_baseline["first_losses"]
+        cpu_baseline["parity_first_losses_max_rel_diff"] = max(abs(g - c) / abs(c) for g, c in zip(first_losses, cpu_first))
+        cpu_baseline["parity_first_losses_within_1e-5"] = bool(cpu_baseline["parity_first_losses_max_rel_diff"] < 1e-5)   # north-star tolerance
 
     return {
         "secondary": {"metric": "matmul4096_fwd_bwd_tflops", "value": round(mm_tflops, 2), "unit": "TFLOP/s",
@@ -578,22 +609,24 @@ def cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b):
         model.load_parameters(w0)
         opt = light.optim.AdaBelief(model.parameters(), lr=1e-3)
         xc, tc = CpuTensor.from_numpy(x_np), CpuTensor.from_numpy(onehot_np)
-        n, t0 = 0, time.perf_counter()
+        n, t0, first = 0, time.perf_counter(), []
         while time.perf_counter() - t0 < seconds and n < max_steps:
             loss = light.loss.mse(model(xc), tc)
             opt.zero_grad()
             loss.backward()
             opt.step()
             n += 1
+            if n <= 3:
+                first.append(loss.item())
         assert np.isfinite(loss.item())
-        return n, n / (time.perf_counter() - t0)
+        return n, n / (time.perf_counter() - t0), first
 
-    n_all, all_threads = tape_loop(8.0, 2000)
+    n_all, all_threads, first_losses = tape_loop(8.0, 2000)
     one_thread = n_one = None
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
-            n_one, one_thread = tape_loop(6.0, 2000)
+            n_one, one_thread, _ = tape_loop(6.0, 2000)
     except Exception:                # threadpoolctl missing or BLAS not controllable: report the all-threads number only
         pass
     an, bn = CpuTensor.from_numpy(a.numpy()), CpuTensor.from_numpy(b.numpy())
@@ -621,7 +654,8 @@ def cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b):
             "sample": "%d steps in ~8 s on all BLAS threads%s; matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s"
                       % (n_all, "" if n_one is None else ", %d steps in ~6 s on one" % n_one, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
             "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3),
-            "oracle_tape_free_steps_per_sec": round(oracle_rate, 2), "numpy": np.__version__}
+            "oracle_tape_free_steps_per_sec": round(oracle_rate, 2), "numpy": np.__version__,
+            "first_losses": [round(float(v), 7) for v in first_losses]}
 
 
 if __name__ == "__main__":

@@ -282,22 +282,27 @@ int lg_mse_f32(const float* y, const float* y_hat, float* err, float* loss, int6
  * An nn.Linear with at most 16 output features (a classifier head; reference nn.py:90-96) followed by
  * loss.mse (loss.py:4-12), forward and backward, in two launches.  `relu` != 0: `x` is the PRE-activation of
  * a relu whose output was never materialised (np.maximum(x, 0) is applied on the fly, cpu/ops.py:226).
- *   lg_head_fwd_f32   y = act(x) @ w^T + bias;  err = y + (-target);  loss[0] = (sum err^2 * (1/(rows*outs))) * 0.5
+ *   lg_head_fwd_f32   y = act(x) @ w^T + bias;  err = y + (-target);  row_loss[r] = sum_j err[r][j]^2
  *                     x: [rows, hidden] with row pitch ldx (hidden, ldx multiples of 4; x, w 16-byte aligned;
  *                     outs*hidden*4 <= 64 KiB), w: [outs, hidden] dense, bias: [outs] or NULL, target/y/err:
- *                     [rows, outs] dense.  step_counter (or NULL): an int64 that is incremented once - the
- *                     optimizer's device step number rides along (see lg_adam_multi_dev_f32).
+ *                     [rows, outs] dense, row_loss: [rows].  step_counter (or NULL): an int64 that is incremented
+ *                     once - the optimizer's device step number rides along (see lg_adam_multi_dev_f32).
+ *   lg_mse_finalize_f32   loss[0] = (sum_r row_loss[r] * (1/n)) * 0.5 with n = rows*outs (loss.py:9-10): one small
+ *                     launch, needed only when the loss is read before lg_head_bwd_f32 has run (which finishes it
+ *                     with one extra workgroup, in the same summation order - same bits either way).
  *   lg_head_bwd_f32   dx = g @ w  ([rows, hidden] dense, or NULL);  gpre = dx * (x >= 0)  (relu.backward's result,
  *                     cpu/ops.py:229; or NULL; needs relu != 0);  dw (+)= g^T @ act(x)  ([outs, hidden] dense, or
  *                     NULL);  db (+)= column sums of g  ([outs], or NULL)  - what dot.backward, transpose.backward
- *                     and the bias un-broadcast of func.py:50-56 compute for `act(x) @ w.T(1,0) + b`.
- * Both replace pyopencl launches of the reference's OpenCL backend: kernels.dot (opencl/ops.py:119-132),
+ *                     and the bias un-broadcast of func.py:50-56 compute for `act(x) @ w.T(1,0) + b`;
+ *                     row_loss / loss: both NULL, or the row sums of lg_head_fwd_f32 and where to put the scalar.
+ * They replace pyopencl launches of the reference's OpenCL backend: kernels.dot (opencl/ops.py:119-132),
  * kernels.atom (:285-288) and kernels.reduce (:344-368). */
 int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
-                    float* y, float* err, float* loss, int64_t rows, int64_t hidden, int64_t outs, int64_t* step_counter);
+                    float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs, int64_t* step_counter);
+int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss);
 int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const float* g, const float* w,
                     float* dx, float* gpre, float* dw, int dw_accumulate, float* db, int db_accumulate,
-                    int64_t rows, int64_t hidden, int64_t outs);
+                    int64_t rows, int64_t hidden, int64_t outs, const float* row_loss, float* loss);
 
 /* lg_mse_f32 with the same optional step-counter increment as lg_head_fwd_f32 */
 int lg_mse_bump_f32(const float* y, const float* y_hat, float* err, float* loss, int64_t n, int64_t* step_counter);

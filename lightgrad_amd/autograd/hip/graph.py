@@ -26,7 +26,7 @@ class HipGraph(object):
 
     def __init__(self):
         self._exec = None
-        self._carried, self._deferred = (), ()      # optimizer step counters the recorded kernels advance (HipTensor._graph_replayed)
+        self._counter_events = ()       # what the recorded kernels do to waiting optimizer step counters (HipTensor._graph_replayed)
 
     @contextmanager
     def capture(self):
@@ -52,17 +52,14 @@ class HipGraph(object):
             HipTensor._capture_ended(ok=False)
             _l.check(rc)
         self._exec = handle
-        import weakref
-        carried, deferred = HipTensor._capture_ended()       # also settles increments owed to the step before the capture
-        self._carried = tuple(weakref.ref(c) for c in carried)
-        self._deferred = tuple(weakref.ref(c) for c in deferred)
+        self._counter_events = tuple(HipTensor._capture_ended())      # also settles increments owed to the step before the capture
 
     def replay(self):
         assert self._exec is not None, "nothing captured"
         _l.check(_l._lib.lg_graph_launch(self._exec))
-        if self._carried or self._deferred:
+        if self._counter_events:
             from .tensor import HipTensor
-            HipTensor._graph_replayed(self._carried, self._deferred)
+            HipTensor._graph_replayed(self._counter_events)
 
     def destroy(self):
         if self._exec is not None and _l._lib is not None:

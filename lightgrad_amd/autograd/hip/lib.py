@@ -89,7 +89,8 @@ PROTOTYPES = {
     "lg_head_fwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int64, c_int64, c_int64, c_void_p]),
     "lg_head_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                c_int64, c_int64, c_int64]),
+                                c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "lg_mse_finalize_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "lg_softmax_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
     "lg_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),

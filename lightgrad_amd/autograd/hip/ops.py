@@ -881,6 +881,7 @@ class linear(Function):
         bias = ctx._parents[2] if has_bias else None
         out_f = weight._shape[0]
         g2 = out_grad.reshape(-1, out_f)
+        g2._unfinished_loss = out_grad._unfinished_loss        # a view of the same `err` (see head_mse_forward)
         pre = _lazy_relu_input(x) if g2._shape[0] > 0 else None
         if pre is not None:
             return linear._backward_through_lazy_relu(x, pre, weight, bias, g2)
@@ -976,13 +977,14 @@ linear._backward_through_lazy_relu = staticmethod(_linear_backward_through_lazy_
 
 
 def _head_eligible(x, weight, bias) -> bool:
-    """a Linear small enough for csrc/head.hip: dense 2-D fp32 input (or pre-activation), <= 16 output features, the
-    alignment its float4 loads need and a weight matrix that fits the 64 KiB LDS stage"""
+    """a Linear small enough for csrc/head.hip: dense 2-D fp32 input (or pre-activation) of at most 4096 rows (the weight
+    gradient is reduced over ALL rows by one workgroup per 8 columns: beyond that the MFMA GEMM is the better tool),
+    <= 16 output features, the alignment its float4 loads need and a weight matrix that fits the 64 KiB LDS stage"""
     if len(x._shape) != 2 or len(weight._shape) != 2 or x._dtype != _F32 or weight._dtype != _F32:
         return False
     rows, hidden = x._shape
     outs = weight._shape[0]
-    if rows < 1 or not 1 <= outs <= 16 or hidden < 4 or hidden % 4 or outs * hidden * 4 > 65536 or weight._shape[1] != hidden:
+    if rows < 1 or rows > 4096 or not 1 <= outs <= 16 or hidden < 4 or hidden % 4 or outs * hidden * 4 > 65536 or weight._shape[1] != hidden:
         return False
     if not (x.is_contiguous() and weight.is_contiguous()) or (bias is not None and not (bias.is_contiguous() and bias._dtype == _F32)):
         return False
@@ -998,11 +1000,16 @@ def head_mse_forward(y, y_hat):
     y_hat = y_hat.contiguous()
     rows, hidden = x._shape
     outs = weight._shape[0]
-    out, err, loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty(())
+    out, err, row_loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty((rows,), requires_grad=False)
     counter = HipTensor._take_deferred_step_advance()
     _l.check(_l.lib().lg_head_fwd_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
-                                      out.ptr, err.ptr, loss.ptr, rows, hidden, outs, counter.ptr if counter is not None else None))
+                                      out.ptr, err.ptr, row_loss.ptr, rows, hidden, outs, counter.ptr if counter is not None else None))
     y._data, y._offset, y._lazy_source = out._data, out._offset, None           # y is real now
+    # the scalar loss stays lazy: the backward launch of this head finishes it (a cross-workgroup sum inside the forward
+    # launch would cost 4 us); whoever reads it before that pays one small launch
+    loss = HipTensor(None, (), None, 0, _F32)
+    loss._lazy_source = ("mse_rows", row_loss, rows * outs)
+    err._unfinished_loss = weakref.ref(loss)
     return loss, err
 
 
@@ -1023,12 +1030,21 @@ def _head_backward(x, src, relu, weight, bias, g2):
     db = (acc_b if acc_b is not None else HipTensor.empty((outs,))) if want_db else None
     dx = HipTensor.empty((rows, hidden)) if x.requires_grad else None
     gpre = HipTensor.empty((rows, hidden)) if (relu and dx is not None) else None
+    # g2 is the `err` of a fused head + mse forward whose scalar loss nobody has looked at yet: finish it in this launch
+    loss = g2._unfinished_loss() if g2._unfinished_loss is not None else None
+    row_loss = loss_out = None
+    if loss is not None and loss._data is None and loss._lazy_source is not None and loss._lazy_source[0] == "mse_rows" \
+            and loss._lazy_source[1]._shape == (rows,) and loss._lazy_source[2] == rows * outs:
+        row_loss, loss_out = loss._lazy_source[1], HipTensor.empty((), requires_grad=False)
     _l.check(_l.lib().lg_head_bwd_f32(
         src.ptr, hidden, 1 if relu else 0, g2.ptr, weight.ptr,
         dx.ptr if dx is not None else None, gpre.ptr if gpre is not None else None,
         dw.ptr, 1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
         db.ptr if db is not None else None, 1 if (acc_b is not None and not bias._consume_zero_pending()) else 0,
-        rows, hidden, outs))
+        rows, hidden, outs, row_loss.ptr if row_loss is not None else None, loss_out.ptr if loss_out is not None else None))
+    if loss_out is not None:
+        loss._data, loss._offset, loss._lazy_source = loss_out._data, loss_out._offset, None
+        g2._unfinished_loss = None
     if acc_w is not None:
         weight._notify_grad_written()
     if acc_b is not None:

@@ -163,6 +163,9 @@ class HipTensor(AbstractTensor):
     #   ("head", x, relu, weight, bias)  created by linear.forward for a skinny output layer (<= 16 features):
     #                                    act(x) @ weight^T + bias, act = relu if `relu` else identity; loss.mse computes
     #                                    it together with the loss in one launch (csrc/head.hip)
+    #   ("mse_rows", row_loss, n)        the scalar loss of that launch: (sum(row_loss) * (1/n)) * 0.5.  The backward
+    #                                    launch of the head finishes it with a spare workgroup; reading it earlier costs
+    #                                    one small launch (lg_mse_finalize_f32)
     # Anything else that asks for `data` / `ptr` runs the plain kernel first - so a lazy tensor behaves like any other
     # everywhere, it just costs nothing until someone looks.  In-place writers into the sources' storage compute the
     # waiting tensor first (flush_lazy_readers), so it is a snapshot like the reference's eager result.
@@ -171,6 +174,10 @@ class HipTensor(AbstractTensor):
     # set on a gradient tensor by the kernel that produced it when the same launch already wrote relu.backward's result
     # for it: (t, out_grad * (t >= 0)) - relu.backward of exactly that t then returns the second tensor without a launch
     _relu_bwd_done = None
+
+    # set on the `err` tensor of a fused head + mse forward: weak reference to the loss tensor whose scalar is not finished
+    # yet (`("mse_rows", ...)` above) - the head's backward launch, which receives err as its gradient, finishes it
+    _unfinished_loss = None
 
     @property
     def data(self):
@@ -188,6 +195,10 @@ class HipTensor(AbstractTensor):
             src = self._lazy_source[1]
             out = HipTensor.empty(self._shape, requires_grad=False)
             _ops._ew(_l.EW_RELU, self._shape, [src], out=out)
+        elif kind == "mse_rows":
+            _, row_loss, n = self._lazy_source
+            out = HipTensor.empty((), requires_grad=False)
+            _l.check(_l.lib().lg_mse_finalize_f32(row_loss.ptr, row_loss.numel(), n, out.ptr))
         else:
             assert kind == "head"
             _, x, relu, weight, bias = self._lazy_source
@@ -447,15 +458,15 @@ class HipTensor(AbstractTensor):
     # such kernel came by, the optimizer flushes the increment itself before it reads the counter again.
     #
     # hipGraph capture (autograd/hip/graph.py calls _capture_begins / _capture_ended / _graph_replayed): a capture pass
-    # executes nothing, so the list is restored when it ends, and what the recorded kernels do to it is replayed with them:
-    #   * a loss kernel recorded in the capture carried the waiting increment -> an optimizer recorded after it defers again
-    #     (warm capture of a whole training step: the graph holds exactly one increment and no launch for it); every
-    #     replay takes one waiting entry and adds one
+    # executes nothing, so the list is restored when it ends, and what the recorded kernels do to it - in order - is
+    # replayed with them:
+    #   * a loss kernel recorded in the capture carried a waiting increment -> an optimizer recorded after it defers again
+    #     (warm capture of one or several whole training steps: one increment per recorded step and no launch for it)
     #   * nothing carried it -> the optimizer records its own 1-thread increment in the graph, as it would eagerly
     #   * an increment of the step BEFORE the capture that no recorded kernel carried is executed once, when the capture
     #     has ended (it belongs to that step, not to every replay)
     _deferred_step_advances = []          # weak references: a counter dies with its optimizer
-    _capture_state = None                 # during a capture: {"snapshot", "carried", "deferred", "owed"}
+    _capture_state = None                 # during a capture: {"snapshot", "own", "events", "owed"}
 
     @staticmethod
     def _waiting_step_counters():
@@ -465,36 +476,42 @@ class HipTensor(AbstractTensor):
         return [c for _, c in alive if c is not None]
 
     @staticmethod
-    def _drop_waiting(step_counter) -> bool:
+    def _drop_waiting(step_counter):
+        """remove the oldest waiting entry of this counter; returns the entry (a weakref) or None"""
         pending = HipTensor._deferred_step_advances
         for i, ref in enumerate(pending):
             if ref() is step_counter:
                 del pending[i]
-                return True
-        return False
+                return ref
+        return None
 
     @staticmethod
     def _advance_step_counter(step_counter, delta: int = 1, defer: bool = False) -> None:
         if defer and delta == 1:
             import weakref
             cap = HipTensor._capture_state
-            if cap is None:
-                HipTensor._deferred_step_advances.append(weakref.ref(step_counter))
-                return
-            if any(c is step_counter for c in cap["carried"]):
-                cap["deferred"].append(step_counter)
+            if cap is None or any(kind == "take" and ref() is step_counter for kind, ref in cap["events"]):
+                entry = weakref.ref(step_counter)
+                HipTensor._deferred_step_advances.append(entry)
+                if cap is not None:
+                    cap["own"].append(entry)
+                    cap["events"].append(("defer", entry))
                 return
         _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, delta))
 
     @staticmethod
     def _flush_step_counter(step_counter) -> None:
         """the optimizer is about to read `step_counter`: enqueue an increment that is still waiting for a carrier"""
-        if HipTensor._drop_waiting(step_counter):
-            cap = HipTensor._capture_state
-            if cap is not None:
-                cap["owed"].append(step_counter)          # belongs to the step before the capture: executed once, afterwards
-            else:
-                _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, 1))
+        entry = HipTensor._drop_waiting(step_counter)
+        if entry is None:
+            return
+        cap = HipTensor._capture_state
+        if cap is not None and not any(entry is e for e in cap["own"]):
+            cap["owed"].append(step_counter)              # belongs to the step before the capture: executed once, afterwards
+            return
+        if cap is not None:
+            cap["events"].append(("take", entry))         # deferred inside this capture, settled inside it: recorded launch
+        _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, 1))
 
     @staticmethod
     def _take_deferred_step_advance():
@@ -504,39 +521,39 @@ class HipTensor(AbstractTensor):
         if HipTensor._deferred_step_advances and Gradients._disable_depth == 1:
             waiting = HipTensor._waiting_step_counters()
             if waiting:
-                del HipTensor._deferred_step_advances[0]
+                entry = HipTensor._deferred_step_advances.pop(0)
                 if HipTensor._capture_state is not None:
-                    HipTensor._capture_state["carried"].append(waiting[0])
+                    HipTensor._capture_state["events"].append(("take", entry))
                 return waiting[0]
         return None
 
     @staticmethod
     def _capture_begins() -> None:
-        HipTensor._capture_state = {"snapshot": list(HipTensor._deferred_step_advances), "carried": [], "deferred": [], "owed": []}
+        HipTensor._capture_state = {"snapshot": list(HipTensor._deferred_step_advances), "own": [], "events": [], "owed": []}
 
     @staticmethod
     def _capture_ended(ok: bool = True):
         """restore the waiting list (the capture pass executed nothing), settle what is owed to the step before the
-        capture, and hand the graph what its recorded kernels do per replay: (counters carried, counters deferred)"""
+        capture, and hand the graph what its recorded kernels do to the list per replay: [("take" | "defer", counter ref)]"""
         cap, HipTensor._capture_state = HipTensor._capture_state, None
         HipTensor._deferred_step_advances[:] = cap["snapshot"]
         if not ok:
-            return [], []
+            return []
         for counter in cap["owed"]:
             HipTensor._drop_waiting(counter)
             _l.check(_l.lib().lg_counter_add_i64(counter.ptr, 1))
-        return cap["carried"], cap["deferred"]
+        return cap["events"]
 
     @staticmethod
-    def _graph_replayed(carried, deferred) -> None:
+    def _graph_replayed(events) -> None:
         import weakref
-        for ref in carried:
+        for kind, ref in events:
             c = ref()
-            if c is not None:
+            if c is None:
+                continue
+            if kind == "take":
                 HipTensor._drop_waiting(c)
-        for ref in deferred:
-            c = ref()
-            if c is not None:
+            else:
                 HipTensor._deferred_step_advances.append(weakref.ref(c))
 
     def __repr__(self):

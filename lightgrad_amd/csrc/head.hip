@@ -4,25 +4,51 @@
 // does 10 MFLOP, so as MFMA tiles it was pure launch latency (forward 9.8, loss 4.9, dW+db 11.5, dh 5.9,
 // relu-backward 5.2 us).  Here:
 //
-//   head_fwd   y = act(x) @ W^T + b,  err = y + (-target),  loss = (sum err^2 * (1/N)) * 0.5
-//              one wavefront per row (lanes split K, W staged once per workgroup in LDS, butterfly sum),
-//              the loss folded inside the launch (per-workgroup partial, ticket, last arriver sums in index order)
-//              - nn.py:96 + loss.py:4-10 of the reference.  Optionally advances a device step counter (the
-//              optimizer's, see optim.hip) - a kernel that runs once per step carries that increment for free.
+//   head_fwd   y = act(x) @ W^T + b,  err = y + (-target),  row_loss[r] = sum_j err[r][j]^2
+//              one wavefront per row (lanes split K, W staged once per workgroup in LDS, butterfly sum)
+//              - nn.py:96 + loss.py:4-8 of the reference.  The scalar loss (sum row_loss * (1/N)) * 0.5 (loss.py:9-10) is
+//              NOT folded here: a cross-workgroup hand-off inside the launch costs 4 us (measured: 9.0 us with it, 5.0
+//              without; an empty launch is 3.0) - it is finished by one extra workgroup of head_bwd, or by
+//              lg_mse_finalize_f32 when somebody reads the loss first.  Optionally advances a device step counter
+//              (the optimizer's, see optim.hip): a kernel that runs once per step carries that increment for free.
 //   head_bwd   dx = g @ W,  g_pre = dx * (pre >= 0),  dW = g^T @ act(x),  db = column sums of g
-//              64 x 32 tiles of (rows x hidden): every element of dx needs only its row of g and its column of W;
-//              dW / db are reduced over the tile's rows in registers + LDS, then over the row blocks inside the
-//              launch (write-through partial slabs, one ticket per column block, fixed summation order)
+//              one launch, three kinds of workgroups, no hand-off between them: "slab" workgroups own 8 columns of dW
+//              over ALL rows (g staged in LDS, sums over thread rows through LDS in a fixed order), "tile" workgroups
+//              write 64 x 32 tiles of dx / g_pre (every element needs only its row of g and its column of W), and one
+//              workgroup finishes the loss of the forward pass
 //              - what linear.backward + relu.backward of the tape compute (cpu/ops.py:114-116, :229, func.py:50-56).
 //
-// act = relu when the tape's relu is still lazy (autograd/hip/ops.py), identity otherwise.  Products and sums are
-// plain fp32 operations in a fixed order (no contraction, -ffp-contract=off): results agree with the GEMM form to
-// rounding (<= 1e-6 relative), and are bit-reproducible from run to run.
+// act = relu when the tape's relu is still lazy (autograd/hip/ops.py), identity otherwise.  The dot products are chains
+// of fused multiply-adds in a fixed order (like the BLAS / MFMA GEMMs they replace, they are not expression-by-expression
+// restatements of numpy ufuncs): results agree with the GEMM form to rounding (<= 1e-6 relative) and are
+// bit-reproducible from run to run.  Everything elementwise (bias add, err, the relu mask) rounds once per operation
+// like the tape's ops.
 #include "common.h"
+#include <cstdlib>
 
 namespace lg {
 
 __device__ __forceinline__ float relu_keep_nan(float x) { return (x != x) ? x : (x > 0.0f ? x : 0.0f); }   // np.maximum(x, 0)
+
+// (sum_r row_loss[r] * inv_n) * 0.5 by ONE workgroup of 256 threads, always in the same order: thread t takes rows
+// t, t+256, ..., then a butterfly over the wavefront, then the four wavefronts.  Shared by head_bwd's loss workgroup and
+// by mse_finalize, so the loss has the same bits whoever finishes it.
+__device__ __forceinline__ void finalize_loss(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss,
+                                              float* lds4) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v = 0.f;
+    for (int64_t i = tid; i < rows; i += 256) v += row_loss[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    if (tid == 0) loss[0] = (((lds4[0] + lds4[1]) + (lds4[2] + lds4[3])) * inv_n) * 0.5f;
+}
+
+__global__ void __launch_bounds__(256) mse_finalize(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss) {
+    __shared__ float lds4[4];
+    finalize_loss(row_loss, rows, inv_n, loss, lds4);
+}
 
 struct HeadFwd {
     const float* x;        // [rows, hidden], row pitch ldx
@@ -31,25 +57,20 @@ struct HeadFwd {
     const float* target;   // [rows, outs] dense
     float*       y;        // [rows, outs]
     float*       err;      // [rows, outs]
-    float*       loss;     // [1]
-    float*       partial;  // [gridDim.x]
-    int*         ticket;   // zero on entry and on exit
+    float*       row_loss; // [rows]
     int64_t*     bump;     // optional: bump[0] += 1 (once per launch)
     int64_t      rows, ldx;
     int          hidden, outs, relu;
-    float        inv_n;
 };
 
 template <int OMAX>
 __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];          // [outs][hidden]
-    __shared__ float wave_part[4];
-    __shared__ int arrived_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = a.outs * a.hidden;
     for (int i = tid * 4; i < wn; i += 1024) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(a.w + i);
+    if (a.bump && blockIdx.x == 0 && tid == 0) a.bump[0] += 1;             // nobody else in this launch looks at it
     __syncthreads();
-    float wave_acc = 0.f;                                                   // sum of err^2 over this wave's rows
     for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < a.rows; row += int64_t(gridDim.x) * 4) {
         float acc[OMAX];
 #pragma unroll
@@ -62,7 +83,7 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
             for (int j = 0; j < OMAX; ++j) {
                 if (j < a.outs) {
                     const float4 w = *reinterpret_cast<const float4*>(w_lds + j * a.hidden + k);
-                    acc[j] += (h.x * w.x + h.y * w.y) + (h.z * w.z + h.w * w.w);
+                    acc[j] = __builtin_fmaf(h.x, w.x, __builtin_fmaf(h.y, w.y, __builtin_fmaf(h.z, w.z, __builtin_fmaf(h.w, w.w, acc[j]))));
                 }
             }
         }
@@ -83,34 +104,7 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);          // OMAX <= 16: lanes 0..15
-        wave_acc += e2;
-    }
-    if (lane == 0) wave_part[wave] = wave_acc;
-    __syncthreads();
-    if (tid == 0) {
-        const float v = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
-        __hip_atomic_store(a.partial + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int order = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = order == int(gridDim.x) - 1;
-        if (last) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        arrived_last = last;
-    }
-    __syncthreads();
-    if (!arrived_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the last workgroup to arrive: sum the partials, thread t taking t, t+256, ... then a fixed tree
-    float v = 0.f;
-    for (int i = tid; i < int(gridDim.x); i += 256) v += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if (lane == 0) wave_part[wave] = v;
-    __syncthreads();
-    if (tid == 0) {
-        const float total = (wave_part[0] + wave_part[1]) + (wave_part[2] + wave_part[3]);
-        a.loss[0] = (total * a.inv_n) * 0.5f;
-        if (a.bump) a.bump[0] += 1;
+        if (lane == 0) a.row_loss[row] = e2;
     }
 }
 
@@ -122,130 +116,149 @@ struct HeadBwd {
     float*       gpre;     // [rows, hidden] dense or NULL: dx * (x >= 0), relu.backward's result (relu != 0 only)
     float*       dw;       // [outs, hidden] dense or NULL
     float*       db;       // [outs] or NULL
-    float*       slabs;    // [col_blocks][row_blocks][OMAX][33]
-    int*         tickets;  // one per column block, zero on entry and on exit
+    const float* row_loss; // [rows] from head_fwd, or NULL
+    float*       loss;     // [1]: finished from row_loss by the launch's last workgroup
+    float        inv_n;
     int64_t      rows, ldx;
-    int          hidden, outs, relu, dw_accumulate, db_accumulate, row_blocks;
+    int          hidden, outs, relu, dw_accumulate, db_accumulate;
+    int          n_slabs;      // workgroups 0 .. n_slabs-1 reduce dW / db, then n_tiles write dx / gpre tiles, then the loss
+    int          n_tiles;
+    int          col_blocks;   // dx tiles per row of tiles
+    int          g_dense;      // outs == OMAX and g 16-byte aligned: g is staged with float4 copies
 };
 
-constexpr int kHeadRows = 64, kHeadCols = 32;
+constexpr int kHeadRows = 64, kHeadCols = 32;     // dx / gpre tile
+constexpr int kSlabCols = 8;                      // columns of dW one reducing workgroup owns (over ALL rows)
 
+// Kinds of workgroups in one launch, none of which waits for another:
+//   slab workgroups  own 8 columns of dW for every row: 32 thread rows x 8 columns, g staged in LDS in chunks of up to
+//                    1024 rows, the activations of a chunk requested from memory before the chunk's g is staged (both
+//                    latencies overlap), sums over the thread rows through LDS in a fixed order.  No cross-workgroup
+//                    reduction, so no tickets and no partial slabs.  (Measured on the way here, 1024 x 512 x 10: a version
+//                    that reduced 64-row tiles across workgroups inside the launch took 14.3 us; this layout with g
+//                    staged element by element 13.3 us, of which 6.2 us were the staging loop - hence the float4 copy -
+//                    and 2.4 us the multiply-adds - hence FMA.)
+//   tile workgroups  write 64 x 32 tiles of dx (and gpre): each element needs its row of g and its column of W only.
+//   loss workgroup   the last one: finishes the scalar loss of head_fwd from its row sums.
 template <int OMAX>
 __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
-    __shared__ float g_lds[kHeadRows][OMAX];
-    __shared__ float w_lds[OMAX][kHeadCols];
-    __shared__ float red[8][OMAX][kHeadCols + 1];
-    __shared__ int arrived_last;
-    const int tid = threadIdx.x, tc = tid & 31, tr = tid >> 5;
-    const int cb = blockIdx.x, rb = blockIdx.y;
+    constexpr int CHUNK = OMAX <= 10 ? 1024 : 512;             // rows of g in LDS at a time (40 KiB / 32 KiB)
+    constexpr int RPT = CHUNK / 32;                            // rows per thread and chunk
+    __shared__ __attribute__((aligned(16))) float g_lds[CHUNK * OMAX];
+    __shared__ float red[32 * OMAX * (kSlabCols + 1)];
+    const int tid = threadIdx.x;
+    if (int(blockIdx.x) < a.n_slabs) {
+        const int tc = tid & 7, tr = tid >> 3;
+        const int slab = blockIdx.x;
+        const int k = slab * kSlabCols + tc;
+        const bool kin = k < a.hidden;
+        const bool does_db = slab == 0 && tc == 0;
+        float acc[OMAX], dbacc[OMAX];
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) { acc[j] = 0.f; dbacc[j] = 0.f; }
+        for (int64_t c0 = 0; c0 < a.rows; c0 += CHUNK) {
+            float xv[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int64_t r = c0 + tr + 32 * i;
+                xv[i] = (r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
+            }
+            __syncthreads();                                   // the previous chunk's g has been consumed
+            const int64_t live = (a.rows - c0 < CHUNK ? a.rows - c0 : CHUNK) * OMAX;      // floats of g in this chunk
+            if (a.g_dense) {
+                const float* src = a.g + c0 * OMAX;            // 16-byte aligned: c0 is a multiple of CHUNK
+                for (int i = tid * 4; i < CHUNK * OMAX; i += 1024) {
+                    float4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (i + 3 < live) v = *reinterpret_cast<const float4*>(src + i);
+                    else if (i < live) { v.x = src[i]; if (i + 1 < live) v.y = src[i + 1]; if (i + 2 < live) v.z = src[i + 2]; }
+                    *reinterpret_cast<float4*>(g_lds + i) = v;
+                }
+            } else {
+                for (int i = tid; i < CHUNK * OMAX; i += 256) {
+                    const int rr = i / OMAX, j = i % OMAX;
+                    g_lds[i] = (j < a.outs && c0 + rr < a.rows) ? a.g[(c0 + rr) * a.outs + j] : 0.f;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int rr = tr + 32 * i;
+                const float h = a.relu ? relu_keep_nan(xv[i]) : xv[i];
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j) acc[j] = __builtin_fmaf(g_lds[rr * OMAX + j], h, acc[j]);
+            }
+            if (does_db) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i)
+#pragma unroll
+                    for (int j = 0; j < OMAX; ++j) dbacc[j] += g_lds[(tr + 32 * i) * OMAX + j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) {
+            red[(tr * OMAX + j) * (kSlabCols + 1) + tc] = acc[j];
+            if (does_db) red[(tr * OMAX + j) * (kSlabCols + 1) + kSlabCols] = dbacc[j];
+        }
+        __syncthreads();
+        if (tid < OMAX * (kSlabCols + 1)) {
+            const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
+            if (j < a.outs && (c < kSlabCols || slab == 0)) {
+                float s = 0.f;
+                for (int t = 0; t < 32; ++t) s += red[(t * OMAX + j) * (kSlabCols + 1) + c];
+                if (c < kSlabCols) {
+                    const int kk = slab * kSlabCols + c;
+                    if (a.dw && kk < a.hidden) {
+                        float* d = a.dw + int64_t(j) * a.hidden + kk;
+                        *d = a.dw_accumulate ? *d + s : s;
+                    }
+                } else if (a.db) {
+                    a.db[j] = a.db_accumulate ? a.db[j] + s : s;
+                }
+            }
+        }
+        return;
+    }
+    if (int(blockIdx.x) >= a.n_slabs + a.n_tiles) {            // the loss workgroup
+        finalize_loss(a.row_loss, a.rows, a.inv_n, a.loss, red);
+        return;
+    }
+    // ---- dx / gpre tile ----
+    float* w_lds = red;                                         // [OMAX][kHeadCols]
+    const int t = int(blockIdx.x) - a.n_slabs;
+    const int cb = t % a.col_blocks;
+    const int64_t r0 = int64_t(t / a.col_blocks) * kHeadRows;
+    const int tc = tid & 31, tr = tid >> 5;
     const int k = cb * kHeadCols + tc;
     const bool kin = k < a.hidden;
+    float xv[kHeadRows / 8];
+#pragma unroll
+    for (int i = 0; i < kHeadRows / 8; ++i) {
+        const int64_t r = r0 + tr + 8 * i;
+        xv[i] = (a.gpre && r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
+    }
     for (int i = tid; i < OMAX * kHeadCols; i += 256) {
         const int j = i / kHeadCols, c = i % kHeadCols;
         const int kk = cb * kHeadCols + c;
-        w_lds[j][c] = (j < a.outs && kk < a.hidden) ? a.w[int64_t(j) * a.hidden + kk] : 0.f;
+        w_lds[i] = (j < a.outs && kk < a.hidden) ? a.w[int64_t(j) * a.hidden + kk] : 0.f;
     }
-    float acc[OMAX], w[OMAX], dbacc = 0.f;
-#pragma unroll
-    for (int j = 0; j < OMAX; ++j) acc[j] = 0.f;
-    const int64_t tiles = (a.rows + kHeadRows - 1) / kHeadRows;
-    for (int64_t tile = rb; tile < tiles; tile += a.row_blocks) {
-        const int64_t r0 = tile * kHeadRows;
-        __syncthreads();                                                   // w_lds staged / previous tile's g_lds consumed
-        for (int i = tid; i < kHeadRows * OMAX; i += 256) {
-            const int rr = i / OMAX, j = i % OMAX;
-            g_lds[rr][j] = (j < a.outs && r0 + rr < a.rows) ? a.g[(r0 + rr) * a.outs + j] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < OMAX; ++j) w[j] = w_lds[j][tc];
-        if (cb == 0 && tid < OMAX) {                                       // bias gradient: column sums of g
-            float s = 0.f;
-            for (int rr = 0; rr < kHeadRows; ++rr) s += g_lds[rr][tid];
-            dbacc += s;
-        }
-#pragma unroll
-        for (int i = 0; i < kHeadRows / 8; ++i) {
-            const int rr = tr + 8 * i;
-            const int64_t r = r0 + rr;
-            if (r < a.rows && kin) {
-                const float xv = a.x[r * a.ldx + k];
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < OMAX; ++j) s += g_lds[rr][j] * w[j];
-                if (a.dx) a.dx[r * a.hidden + k] = s;
-                if (a.gpre) a.gpre[r * a.hidden + k] = s * (xv >= 0.0f ? 1.0f : 0.0f);
-                const float h = a.relu ? relu_keep_nan(xv) : xv;
-#pragma unroll
-                for (int j = 0; j < OMAX; ++j) acc[j] += g_lds[rr][j] * h;
-            }
-        }
+    for (int i = tid; i < kHeadRows * OMAX; i += 256) {
+        const int rr = i / OMAX, j = i % OMAX;
+        g_lds[i] = (j < a.outs && r0 + rr < a.rows) ? a.g[(r0 + rr) * a.outs + j] : 0.f;
     }
-    if (a.dw == nullptr && a.db == nullptr) return;
-    // rows of this workgroup: 8 thread rows -> one value per (output j, column)
-#pragma unroll
-    for (int j = 0; j < OMAX; ++j) red[tr][j][tc] = acc[j];
-    if (cb == 0 && tid < OMAX) red[0][tid][kHeadCols] = dbacc;
     __syncthreads();
-    constexpr int SLAB = OMAX * (kHeadCols + 1);
-    float* mine = a.slabs + (int64_t(cb) * a.row_blocks + rb) * SLAB;
-    for (int i = tid; i < SLAB; i += 256) {
-        const int j = i / (kHeadCols + 1), c = i % (kHeadCols + 1);
-        float s;
-        if (c < kHeadCols) {
-            s = red[0][j][c];
+    float w[OMAX];
 #pragma unroll
-            for (int t = 1; t < 8; ++t) s += red[t][j][c];
-        } else {
-            s = cb == 0 ? red[0][j][kHeadCols] : 0.f;
-        }
-        if (a.row_blocks == 1) red[0][j][c] = s;                          // nothing to fold: hand over through LDS
-        else __hip_atomic_store(mine + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (a.row_blocks > 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            int* ticket = a.tickets + cb;
-            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = order == a.row_blocks - 1;
-            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrived_last = last;
-        }
-        __syncthreads();
-        if (!arrived_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else {
-        __syncthreads();
-    }
-    // fold the row blocks in index order and write this column block of dW (and db from column block 0)
-    const float* base = a.slabs + int64_t(cb) * a.row_blocks * SLAB;
-    for (int i = tid; i < SLAB; i += 256) {
-        const int j = i / (kHeadCols + 1), c = i % (kHeadCols + 1);
-        if (j >= a.outs) continue;
-        float s;
-        if (a.row_blocks == 1) {
-            s = red[0][j][c];
-        } else {
-            s = 0.f;
-            int b = 0;
-            for (; b + 3 < a.row_blocks; b += 4) {                        // four loads in flight, summed in order
-                const float v0 = __hip_atomic_load(base + int64_t(b) * SLAB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float v1 = __hip_atomic_load(base + int64_t(b + 1) * SLAB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float v2 = __hip_atomic_load(base + int64_t(b + 2) * SLAB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float v3 = __hip_atomic_load(base + int64_t(b + 3) * SLAB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s = (((s + v0) + v1) + v2) + v3;
-            }
-            for (; b < a.row_blocks; ++b) s += __hip_atomic_load(base + int64_t(b) * SLAB + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (c < kHeadCols) {
-            const int kk = cb * kHeadCols + c;
-            if (a.dw && kk < a.hidden) {
-                float* d = a.dw + int64_t(j) * a.hidden + kk;
-                *d = a.dw_accumulate ? *d + s : s;
-            }
-        } else if (cb == 0 && a.db) {
-            a.db[j] = a.db_accumulate ? a.db[j] + s : s;
+    for (int j = 0; j < OMAX; ++j) w[j] = w_lds[j * kHeadCols + tc];
+#pragma unroll
+    for (int i = 0; i < kHeadRows / 8; ++i) {
+        const int rr = tr + 8 * i;
+        const int64_t r = r0 + rr;
+        if (r < a.rows && kin) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) s = __builtin_fmaf(g_lds[rr * OMAX + j], w[j], s);
+            if (a.dx) a.dx[r * a.hidden + k] = s;
+            if (a.gpre) a.gpre[r * a.hidden + k] = s * (xv[i] >= 0.0f ? 1.0f : 0.0f);
         }
     }
 }
@@ -255,71 +268,70 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
 using namespace lg;
 
 extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
-                               float* y, float* err, float* loss, int64_t rows, int64_t hidden, int64_t outs,
+                               float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs,
                                int64_t* step_counter) {
     LG_REQUIRE_INIT();
     LG_ARG(rows > 0 && hidden > 0 && outs > 0 && outs <= 16, "lg_head_fwd_f32: need rows > 0, hidden > 0, 1 <= outs <= 16 (got %lld, %lld, %lld)",
            (long long)rows, (long long)hidden, (long long)outs);
-    LG_ARG(x && w && target && y && err && loss, "lg_head_fwd_f32: NULL pointer");
+    LG_ARG(x && w && target && y && err && row_loss, "lg_head_fwd_f32: NULL pointer");
     LG_ARG(hidden % 4 == 0 && ldx % 4 == 0 && ldx >= hidden && aligned16(x) && aligned16(w),
            "lg_head_fwd_f32: hidden and ldx must be multiples of 4 and x, w 16-byte aligned");
     LG_ARG(outs * hidden * 4 <= 64 * 1024, "lg_head_fwd_f32: W (%lld x %lld) does not fit the 64 KiB LDS stage", (long long)outs, (long long)hidden);
     HeadFwd a{};
-    a.x = x; a.w = w; a.bias = bias; a.target = target; a.y = y; a.err = err; a.loss = loss;
+    a.x = x; a.w = w; a.bias = bias; a.target = target; a.y = y; a.err = err; a.row_loss = row_loss;
     a.rows = rows; a.ldx = ldx; a.hidden = int(hidden); a.outs = int(outs); a.relu = relu;
-    a.inv_n = float(1.0 / double(rows * outs));       // python's `1 / numel` rounded once to fp32 (as lg_mse_f32)
     a.bump = step_counter;
     int64_t grid = (rows + 3) / 4;
     if (grid > 1024) grid = 1024;
-    int rc = lg_malloc(reinterpret_cast<void**>(&a.partial), size_t(grid) * sizeof(float));
-    if (rc != LG_OK) return rc;
-    a.ticket = rt().gemm_tickets;
     const size_t lds = size_t(outs * hidden) * sizeof(float);
     hipStream_t s = rt().stream;
     if (outs <= 4)        hipLaunchKernelGGL(head_fwd<4>, dim3(unsigned(grid)), dim3(256), lds, s, a);
     else if (outs <= 8)   hipLaunchKernelGGL(head_fwd<8>, dim3(unsigned(grid)), dim3(256), lds, s, a);
     else if (outs <= 10)  hipLaunchKernelGGL(head_fwd<10>, dim3(unsigned(grid)), dim3(256), lds, s, a);
     else                  hipLaunchKernelGGL(head_fwd<16>, dim3(unsigned(grid)), dim3(256), lds, s, a);
-    rc = lg_free(a.partial);
-    if (rc != LG_OK) return rc;
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss) {
+    LG_REQUIRE_INIT();
+    LG_ARG(row_loss && loss && rows > 0 && n > 0, "lg_mse_finalize_f32: bad arguments");
+    hipLaunchKernelGGL(mse_finalize, dim3(1), dim3(256), 0, rt().stream, row_loss, rows, float(1.0 / double(n)), loss);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
 
 extern "C" int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const float* g, const float* w,
                                float* dx, float* gpre, float* dw, int dw_accumulate, float* db, int db_accumulate,
-                               int64_t rows, int64_t hidden, int64_t outs) {
+                               int64_t rows, int64_t hidden, int64_t outs, const float* row_loss, float* loss) {
     LG_REQUIRE_INIT();
     LG_ARG(rows > 0 && hidden > 0 && outs > 0 && outs <= 16, "lg_head_bwd_f32: need rows > 0, hidden > 0, 1 <= outs <= 16 (got %lld, %lld, %lld)",
            (long long)rows, (long long)hidden, (long long)outs);
     LG_ARG(x && g && w, "lg_head_bwd_f32: NULL pointer");
     LG_ARG(ldx >= hidden, "lg_head_bwd_f32: ldx < hidden");
     LG_ARG(gpre == nullptr || relu, "lg_head_bwd_f32: gpre is relu.backward's result and needs relu != 0");
+    LG_ARG(hidden < (int64_t(1) << 24), "lg_head_bwd_f32: hidden too large");
+    LG_ARG((row_loss == nullptr) == (loss == nullptr), "lg_head_bwd_f32: row_loss and loss go together");
     HeadBwd a{};
     a.x = x; a.g = g; a.w = w; a.dx = dx; a.gpre = gpre; a.dw = dw; a.db = db;
     a.rows = rows; a.ldx = ldx; a.hidden = int(hidden); a.outs = int(outs); a.relu = relu;
     a.dw_accumulate = dw_accumulate; a.db_accumulate = db_accumulate;
-    const int64_t col_blocks = (hidden + kHeadCols - 1) / kHeadCols;
-    const int64_t tiles = (rows + kHeadRows - 1) / kHeadRows;
-    LG_ARG(col_blocks <= rt().n_gemm_tickets, "lg_head_bwd_f32: hidden too large");
-    // enough workgroups for 256 CUs, but never more row blocks than the last arriver can fold cheaply
-    int64_t row_blocks = (2 * 256 + col_blocks - 1) / col_blocks;
-    if (row_blocks > tiles) row_blocks = tiles;
-    if (row_blocks > 64) row_blocks = 64;
-    if (row_blocks < 1) row_blocks = 1;
-    a.row_blocks = int(row_blocks);
+    a.row_loss = row_loss; a.loss = loss;
+    a.inv_n = float(1.0 / double(rows * outs));       // python's `1 / numel` rounded once to fp32 (as lg_mse_f32)
+    a.n_slabs = dw ? int((hidden + kSlabCols - 1) / kSlabCols) : (db ? 1 : 0);       // the bias gradient alone: slab 0 does it
+    a.col_blocks = int((hidden + kHeadCols - 1) / kHeadCols);
+    const int64_t tiles = (dx || gpre) ? int64_t(a.col_blocks) * ((rows + kHeadRows - 1) / kHeadRows) : 0;
+    const int64_t grid = a.n_slabs + tiles + (loss ? 1 : 0);
+    if (grid == 0) return LG_OK;
+    LG_ARG(grid < (int64_t(1) << 30), "lg_head_bwd_f32: problem too large for one launch");
+    a.n_tiles = int(tiles);
     const int omax = outs <= 4 ? 4 : (outs <= 8 ? 8 : (outs <= 10 ? 10 : 16));
-    int rc = lg_malloc(reinterpret_cast<void**>(&a.slabs), size_t(col_blocks * row_blocks) * omax * (kHeadCols + 1) * sizeof(float));
-    if (rc != LG_OK) return rc;
-    a.tickets = rt().gemm_tickets;
+    a.g_dense = (omax == outs && aligned16(g)) ? 1 : 0;
     hipStream_t s = rt().stream;
-    const dim3 grid{unsigned(col_blocks), unsigned(row_blocks), 1u};
-    if (omax == 4)        hipLaunchKernelGGL(head_bwd<4>, grid, dim3(256), 0, s, a);
-    else if (omax == 8)   hipLaunchKernelGGL(head_bwd<8>, grid, dim3(256), 0, s, a);
-    else if (omax == 10)  hipLaunchKernelGGL(head_bwd<10>, grid, dim3(256), 0, s, a);
-    else                  hipLaunchKernelGGL(head_bwd<16>, grid, dim3(256), 0, s, a);
-    rc = lg_free(a.slabs);
-    if (rc != LG_OK) return rc;
+    if (omax == 4)        hipLaunchKernelGGL(head_bwd<4>, dim3(unsigned(grid)), dim3(256), 0, s, a);
+    else if (omax == 8)   hipLaunchKernelGGL(head_bwd<8>, dim3(unsigned(grid)), dim3(256), 0, s, a);
+    else if (omax == 10)  hipLaunchKernelGGL(head_bwd<10>, dim3(unsigned(grid)), dim3(256), 0, s, a);
+    else                  hipLaunchKernelGGL(head_bwd<16>, dim3(unsigned(grid)), dim3(256), 0, s, a);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -6,7 +6,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-marks = [i for i, n in enumerate(names) if "counter_add" in n or ("adam" in n and False)]
+# a step of the flat-bucket path ends with its ONE multi-tensor optimizer launch; the per-parameter path has four
+marks = [i for i, n in enumerate(names) if "adam_multi_dev" in n]
 if len(marks) < 60:
     marks = [i for i, n in enumerate(names) if "adam" in n][3::4]
 s, e = marks[50] + 1, marks[51] + 1

@@ -88,7 +88,17 @@ struct GemmArgs {
     // relu folded into its consumers (the tape's relu stays lazy, autograd/hip/ops.py): op(A) / op(B) are passed through
     // np.maximum(., 0) on their way to LDS
     int     relu_a, relu_b;
+#ifdef LG_GEMM_TIMELINE
+    // experiments build only (make timeline; tools/gemm_timeline.py): 8 timestamps of the 100 MHz wall clock per workgroup
+    unsigned long long* tl;
+#endif
 };
+
+#ifdef LG_GEMM_TIMELINE
+#define LG_TL(slot) do { if (g.tl && threadIdx.x == 0) g.tl[size_t(blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define LG_TL(slot) do { } while (0)
+#endif
 
 // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous range of
 // tile ids.  Bijective for any nwg (cdna_hip_programming.md T1).
@@ -123,6 +133,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
+    LG_TL(0);                                        // workgroup entered
 
     // tile coordinates
     const int id = xcd_remap(blockIdx.x, g.nwg);
@@ -391,6 +402,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     }
     store_tile(0, 0);
     __syncthreads();
+    LG_TL(1);                                        // first K-tile in LDS
     if constexpr (TM * TN == 1) {
         // One accumulator per wave (small tiles: often ONE such wave per SIMD, nothing else to hide latency behind):
         // the fragments of the next half K-tile are fetched from LDS while the MFMAs of the current half run.  The
@@ -483,6 +495,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         }
     }
 
+    LG_TL(2);                                        // K loop done
     if constexpr (kCanSplitK<BM, BN>) if (g.k_slices > 1) {
         // split-K, folded inside the launch (cdna_hip_programming.md, in-launch split-K recipe, write-through form).
         // Partial tiles go to the workspace in ACCUMULATOR layout - 16-byte piece ((i*TN + j)*4 + q) of thread tid at
@@ -512,6 +525,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
         __syncthreads();
+        LG_TL(3);                                                 // slab written and drained
         int* arrived_last = reinterpret_cast<int*>(lds);          // the staging buffers are free after the K loop's last barrier
         if (tid == 0) {
             int* ticket = g.tickets + batch * per_batch + t;
@@ -521,6 +535,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             *arrived_last = last;
         }
         __syncthreads();
+        LG_TL(4);                                                 // ticket drawn
         if (!*arrived_last) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the slab loads below the ticket
         constexpr int CH = TM * TN >= 4 ? 1 : (TM * TN == 2 ? 2 : 4);     // slices whose loads are in flight together
@@ -549,6 +564,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         }
     }
 
+    LG_TL(5);                                        // slabs folded (or nothing to fold)
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -562,25 +578,33 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 float* const dst = vcol ? g.rowsum : C + col;
                 const int64_t dstride = vcol ? 1 : ldc;
                 const bool acc_flag = vcol ? g.rowsum_accumulate != 0 : accumulate != 0;
-                float old[16];
-                if (acc_flag) {        // C += ...: fetch the 16 old values first so the loads overlap, then add and store
+                // The values first, the stores last, and the read-modify-write of `C += ...` in a block of its own:
+                // on gfx9-family hardware stores count in vmcnt like loads, so when the old-value loads sat in the same
+                // straight-line code as the stores, the wait in front of every add also drained the PREVIOUS store -
+                // 16 serialised store round trips, 2.0 of a 15.6 us launch (tools/gemm_timeline.py).
+                float val[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) val[e] = bias ? acc[i][j][e] + bv : acc[i][j][e];
+                if (acc_flag) {
+                    float old[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
                         old[e] = row < g.M ? dst[row * dstride] : 0.f;
                     }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) val[e] = old[e] + val[e];
                 }
+                float* p = dst + row0 * dstride;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < g.M) {
-                        const float val = bias ? acc[i][j][e] + bv : acc[i][j][e];
-                        dst[row * dstride] = acc_flag ? old[e] + val : val;
-                    }
+                    if (row < g.M) p[((e & 3) + 8 * (e >> 2)) * dstride] = val[e];
                 }
             }
         }
     }
+    LG_TL(6);                                        // epilogue stores issued
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
@@ -593,6 +617,14 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1>), grid, block, 0, s, g);
     else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, 1>), grid, block, 0, s, g);
 }
+
+#ifdef LG_GEMM_TIMELINE
+static unsigned long long* g_tl_buf = nullptr;
+static int g_tl_nwg = 0, g_tl_slices = 0, g_tl_tiles = 0;
+static void lg_debug_timeline_state(unsigned long long* buf, int nwg, int slices, int tiles) {
+    g_tl_buf = buf; g_tl_nwg = nwg; g_tl_slices = slices; g_tl_tiles = tiles;
+}
+#endif
 
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
@@ -631,6 +663,15 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     g.div_batch_inner = make_fastdiv(g.batch_inner);
     g.W = nullptr;
     g.tickets = rt().gemm_tickets;
+#ifdef LG_GEMM_TIMELINE
+    {
+        static unsigned long long* tl_buf = nullptr;
+        if (!tl_buf) (void)hipMalloc(reinterpret_cast<void**>(&tl_buf), size_t(1) << 22);
+        g.tl = (tl_buf && size_t(g.nwg) * 64 <= (size_t(1) << 22)) ? tl_buf : nullptr;
+        if (g.tl) (void)hipMemsetAsync(g.tl, 0, size_t(g.nwg) * 64, rt().stream);
+        lg_debug_timeline_state(tl_buf, g.nwg, g.k_slices, int(tiles));
+    }
+#endif
     if (slices > 1 && tiles > rt().n_gemm_tickets) {       // more tiles than tickets: plenty of workgroups anyway
         slices = 1;
         g.k_per_slice = (g.K + BK - 1) / BK * BK;
@@ -807,3 +848,15 @@ extern "C" int lg_gemm_fused_f32(int transA, int transB, int64_t M, int64_t N, i
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, accumulate, bias, rowsum, rowsum_accumulate,
                      1, 0, 0, 0, relu_a, relu_b);
 }
+
+#ifdef LG_GEMM_TIMELINE
+// experiments build only: timestamps of the LAST GEMM launch (8 x uint64 per workgroup; 100 MHz wall clock)
+extern "C" int lg_debug_gemm_timeline(unsigned long long* host, int max_wgs, int* nwg, int* slices, int* tiles) {
+    LG_REQUIRE_INIT();
+    LG_HIP(hipStreamSynchronize(rt().stream));
+    const int n = lg::g_tl_nwg < max_wgs ? lg::g_tl_nwg : max_wgs;
+    if (lg::g_tl_buf && n > 0) LG_HIP(hipMemcpy(host, lg::g_tl_buf, size_t(n) * 64, hipMemcpyDeviceToHost));
+    *nwg = n; *slices = lg::g_tl_slices; *tiles = lg::g_tl_tiles;
+    return LG_OK;
+}
+#endif

@@ -645,7 +645,19 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         double best = 1e30;
         for (int64_t sl = 1; sl <= 64 && sl * 2 <= k_tiles; ++sl) {
             const double per_cu = double(tiles * sl) / cus;
-            const double cost = double((k_tiles + sl - 1) / sl) * t_iter * (per_cu > 1.0 ? per_cu : 1.0) + (sl > 1 ? 2.0 + 0.6 * double(sl) : 0.0);
+            const double kt = double((k_tiles + sl - 1) / sl);
+            double cost;
+            if (BM * BN == 64 * 64) {
+                // refitted in round 2 from per-workgroup timestamps (tools/gemm_timeline.py, LG_GEMM_SLICES sweep): a lone
+                // 4-wave workgroup needs 0.68 us per K-tile (one wave per SIMD: its waits are idle matrix-core time), c
+                // workgroups sharing a CU need 0.43*c + 0.17 us for one K-tile EACH (their waits interleave; the matrix
+                // cores become the limit), the launch ends with the CUs that host ceil(per_cu) of them; publishing + folding
+                // the slabs costs 1.8 + 0.85*slices us
+                const double c = per_cu > 1.0 ? double(int64_t(per_cu + 0.999)) : 1.0;
+                cost = kt * (c <= 1.0 ? 0.68 : 0.43 * c + 0.17) + (sl > 1 ? 1.8 + 0.85 * double(sl) : 0.0);
+            } else {
+                cost = kt * t_iter * (per_cu > 1.0 ? per_cu : 1.0) + (sl > 1 ? 2.0 + 0.6 * double(sl) : 0.0);
+            }
             if (cost < best) { best = cost; slices = sl; }
         }
     }

@@ -41,6 +41,7 @@ extern "C" {
 #define LG_ENOMEM       -3   /* device allocation failed even after trimming the pool */
 #define LG_ENOTINIT     -4   /* lg_init has not been called */
 #define LG_ECOMM        -5   /* RCCL failure (liblghip_comm.so) */
+#define LG_EINDEX       -6   /* an EARLIER kernel met an index / label out of range (reported by the next synchronising call) */
 
 const char* lg_last_error(void);
 
@@ -277,6 +278,28 @@ int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg
  *   err[i] = y[i] + (-y_hat[i]);   loss[0] = (sum_i err[i]^2 * (1/n)) * 0.5
  * `err` is what mse.backward multiplies by the upstream gradient (loss.py:11-12). */
 int lg_mse_f32(const float* y, const float* y_hat, float* err, float* loss, int64_t n);
+
+/* ---- integer-array indexing along one axis (csrc/index.hip) ------------------------
+ * The dense tensor is seen as [outer][axis_len][inner]; `idx` holds n_idx int16/int32/int64 positions on the
+ * axis (negative = from the end).  They do on the device what the reference's CPU backend does with numpy
+ * (cpu/ops.py:234-255) for Dataset shuffling (data.py:15-21), embedding lookups (examples/bert.py:19-21) and
+ * the label pick / update of loss.cross_entropy (loss.py:19, :22); the reference's OpenCL backend has none.
+ *   lg_take_axis             dst[outer][n_idx][inner]: dst[o][j][i] = src[o][idx[j]][i]         any itemsize
+ *   lg_put_axis              dst[o][idx[j]][i] = val[o][j][i]  (val == NULL: the scalar whose bits are given)
+ *   lg_scatter_add_axis_f32  dst[o][idx[j]][i] += src[o][j][i]  (fp32 atomics: repeated indices accumulate;
+ *                            their order of addition is not fixed, so sums of 3+ contributions may differ in
+ *                            the last bit from run to run - the one non-reproducible kernel of the library)
+ * pair_period = n > 0: the paired form `t[range(n), idx]` - idx has n entries, entry (o mod n) belongs to
+ * outer position o, and the indexed array is [outer][inner] (no n_idx axis).
+ * An index outside [-axis_len, axis_len): take writes all-ones bytes, put / scatter skip it, and the device
+ * status flag is raised - the next lg_sync / lg_memcpy_d2h returns LG_EINDEX (numpy raises IndexError at
+ * once; a kernel cannot). */
+int lg_take_axis(int itemsize, const void* src, int64_t outer, int64_t axis_len, int64_t inner,
+                 const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, void* dst);
+int lg_put_axis(int itemsize, void* dst, int64_t outer, int64_t axis_len, int64_t inner,
+                const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const void* val, uint64_t scalar_bits);
+int lg_scatter_add_axis_f32(float* dst, int64_t outer, int64_t axis_len, int64_t inner,
+                            const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const float* src);
 
 /* ---- the skinny output layer and its loss (csrc/head.hip) ------------------------
  * An nn.Linear with at most 16 output features (a classifier head; reference nn.py:90-96) followed by

@@ -315,7 +315,8 @@ class getitem(Function):
     def backward(ctx, out_grad):
         shape, idx = ctx.get_saved_tensors()
         grad = np.zeros(shape, dtype=np.float32)
-        if isinstance(idx, np.ndarray) and idx.dtype.kind in "iu":
+        parts = idx if isinstance(idx, tuple) else (idx,)
+        if any(isinstance(i, (list, range)) or (isinstance(i, np.ndarray) and i.dtype.kind in "iu") for i in parts):
             # integer-array (embedding) index: repeated ids must ACCUMULATE.  The reference's `grad[idx] = out_grad`
             # (cpu/ops.py:245) keeps only the last occurrence; identical whenever ids are unique.
             np.add.at(grad, idx, out_grad)

@@ -97,6 +97,9 @@ PROTOTYPES = {
     "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_cross_entropy_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_layernorm_param_grads_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int]),
+    "lg_take_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "lg_put_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_uint64]),
+    "lg_scatter_add_axis_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "lg_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
     "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
 }
@@ -158,8 +161,13 @@ def lib():
     return _lib
 
 
+LG_EINDEX = -6
+
+
 def check(rc):
     if rc != 0:
+        if rc == LG_EINDEX:          # what numpy reports at once, a kernel can only report at the next synchronisation
+            raise IndexError(_lib.lg_last_error().decode())
         raise HipError("liblghip error %d: %s" % (rc, _lib.lg_last_error().decode()))
 
 

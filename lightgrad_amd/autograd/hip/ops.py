@@ -618,12 +618,148 @@ class relu(Function):
 """ Selectors """
 
 
+_INT_INDEX_DTYPES = (np.dtype(np.int16), np.dtype(np.int32), np.dtype(np.int64))
+
+
+def _is_advanced(i):
+    return isinstance(i, (list, range, HipTensor)) or (isinstance(i, np.ndarray) and i.ndim > 0)
+
+
+class _TakePlan(object):
+    """integer-array indexing split into a basic view + ONE gather along an axis of that view (csrc/index.hip)"""
+    __slots__ = ("basic", "axis", "index", "pair")
+
+
+def _index_tensor(x, axis_len):
+    """an index given as HipTensor / ndarray / list / range -> dense int HipTensor on the device.  Host-side indices are
+    validated here (IndexError at once, like numpy); device-resident ones by the kernel (status flag, next sync)."""
+    if isinstance(x, HipTensor):
+        if x._dtype not in _INT_INDEX_DTYPES:
+            raise IndexError("index tensors must be int16, int32 or int64 (got %s); boolean masks are not supported" % x._dtype)
+        return x.contiguous()
+    arr = np.asarray(x)
+    if arr.dtype.kind not in "iu":
+        raise IndexError("arrays used as indices must be of integer type (got %s)" % arr.dtype)
+    arr = arr.astype(np.int64)
+    if arr.size and (arr.min() < -axis_len or arr.max() >= axis_len):
+        bad = arr[(arr < -axis_len) | (arr >= axis_len)].flat[0]
+        raise IndexError("index %d is out of bounds for axis with size %d" % (bad, axis_len))
+    return HipTensor.from_numpy(arr, requires_grad=False)
+
+
+def _is_arange(x, n):
+    if isinstance(x, range):
+        return len(x) == n and (n == 0 or (x[0] == 0 and x.step == 1))
+    if isinstance(x, HipTensor):
+        return False
+    arr = np.asarray(x)
+    return arr.ndim == 1 and arr.shape[0] == n and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(n))
+
+
+def _take_plan(a, idx):
+    """None for basic indexing, else the _TakePlan of `a[idx]`.  Supported: any mix of ints / slices / Ellipsis / None with ONE
+    integer-array index (any shape), or with the pair `range(n), labels` on two neighbouring axes (loss.py:19)."""
+    idx = idx if isinstance(idx, tuple) else (idx,)
+    adv = [k for k, i in enumerate(idx) if _is_advanced(i)]
+    if not adv:
+        return None
+    if len(adv) > 2 or (len(adv) == 2 and adv[1] != adv[0] + 1):
+        raise NotImplementedError("HipTensor indexing supports one integer-array index, or the pair `range(n), labels` on "
+                                  "neighbouring axes; got %d array indices" % len(adv))
+    plan = _TakePlan()
+    plan.basic = tuple(slice(None) if _is_advanced(i) else i for i in idx)
+    # axis of the basic VIEW the first array index applies to: entries in front of it that produce a dimension
+    n_real = _py.sum(1 for i in idx if i is not None and i is not Ellipsis)
+    axis = 0
+    for i in idx[:adv[0]]:
+        if i is Ellipsis:
+            axis += len(a._shape) - n_real
+        elif i is None or isinstance(i, slice):
+            axis += 1
+    plan.axis = axis
+    view_shape = _idx_view(a, plan.basic)._shape
+    if len(adv) == 1:
+        plan.pair = False
+        plan.index = _index_tensor(idx[adv[0]], view_shape[axis])
+    else:
+        n = view_shape[axis]
+        if not _is_arange(idx[adv[0]], n):
+            raise NotImplementedError("of two array indices the first must be range(n) over its whole axis (the `y[range(n), labels]` "
+                                      "form of loss.cross_entropy)")
+        plan.pair = True
+        plan.index = _index_tensor(idx[adv[1]], view_shape[axis + 1])
+        if plan.index._shape != (n,):
+            raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes (%d,) %s" % (n, plan.index._shape))
+    return plan
+
+
+def _take_extents(view_shape, plan):
+    """(outer, axis_len, inner, pair_period, result shape) of a plan applied to a dense tensor of `view_shape`"""
+    ax = plan.axis
+    prod = lambda dims: int(np.prod(dims, dtype=np.int64)) if len(dims) else 1      # noqa: E731
+    if plan.pair:
+        n = view_shape[ax]
+        return prod(view_shape[:ax]) * n, view_shape[ax + 1], prod(view_shape[ax + 2:]), n, view_shape[:ax] + (n,) + view_shape[ax + 2:]
+    return prod(view_shape[:ax]), view_shape[ax], prod(view_shape[ax + 1:]), 0, view_shape[:ax] + plan.index._shape + view_shape[ax + 1:]
+
+
+def _take(a, plan):
+    src = _idx_view(a, plan.basic).contiguous()
+    outer, axis_len, inner, period, shape = _take_extents(src._shape, plan)
+    out = HipTensor.empty(shape, dtype=a._dtype)
+    _l.check(_l.lib().lg_take_axis(a._dtype.itemsize, src.ptr, outer, axis_len, inner, plan.index.ptr, plan.index._dtype.itemsize,
+                                   plan.index.numel(), period, out.ptr))
+    return out
+
+
+def _put(a, plan, val):
+    """a[idx] = val for a plan: in place when the basic view is dense, else through a dense copy of the view"""
+    view = _idx_view(a, plan.basic)
+    dense = view if view.is_contiguous() else view.contiguous()
+    outer, axis_len, inner, period, shape = _take_extents(dense._shape, plan)
+    bits, vptr = 0, None
+    if isinstance(val, np.ndarray) and val.ndim > 0:
+        val = HipTensor.from_numpy(val.astype(a._dtype), requires_grad=False)
+    if isinstance(val, HipTensor):
+        assert val._dtype == a._dtype, "setitem: dtype mismatch (%s <- %s)" % (a._dtype, val._dtype)
+        assert _broadcast_shapes(shape, val._shape) == shape, "setitem: value of shape %s does not broadcast to %s" % (val._shape, shape)
+        if val._shape != shape or not val.is_contiguous():
+            full = HipTensor.empty(shape, dtype=a._dtype, requires_grad=False)
+            _l.check(_l.lib().lg_copy_strided(a._dtype.itemsize, len(shape), i64(shape), full.ptr, i64(full._strides), val.ptr,
+                                              i64(_bstrides(val, shape))))
+            val = full
+        vptr = val.ptr
+    else:
+        bits = _value_bits(val, a._dtype)
+    _l.check(_l.lib().lg_put_axis(a._dtype.itemsize, dense.ptr, outer, axis_len, inner, plan.index.ptr, plan.index._dtype.itemsize,
+                                  plan.index.numel(), period, vptr, bits))
+    if dense is not view:
+        _l.check(_l.lib().lg_copy_strided(a._dtype.itemsize, len(view._shape), i64(view._shape), view.ptr, i64(view._strides),
+                                          dense.ptr, i64(dense._strides)))
+
+
+def _scatter_add(grad, plan, out_grad):
+    """grad[idx] += out_grad for a plan (fp32); `grad` is a dense tensor of the indexed tensor's shape"""
+    view = _idx_view(grad, plan.basic)
+    g = out_grad.contiguous()
+    if view.is_contiguous():
+        outer, axis_len, inner, period, shape = _take_extents(view._shape, plan)
+        assert g._shape == shape
+        _l.check(_l.lib().lg_scatter_add_axis_f32(view.ptr, outer, axis_len, inner, plan.index.ptr, plan.index._dtype.itemsize,
+                                                  plan.index.numel(), period, g.ptr))
+        return
+    dense = HipTensor.zeros(view._shape, requires_grad=False)
+    outer, axis_len, inner, period, shape = _take_extents(dense._shape, plan)
+    _l.check(_l.lib().lg_scatter_add_axis_f32(dense.ptr, outer, axis_len, inner, plan.index.ptr, plan.index._dtype.itemsize,
+                                              plan.index.numel(), period, g.ptr))
+    _binary(_l.EW_ADD, view, dense, out=view)
+
+
 def _idx_view(a, idx):
     """basic indexing (ints, slices, Ellipsis, None) as a strided view (opencl/ops.py:299-313, plus steps)"""
     idx = idx if isinstance(idx, tuple) else (idx,)
-    if any(isinstance(i, (list, np.ndarray, HipTensor, range)) for i in idx):
-        raise NotImplementedError("HipTensor supports basic indexing only (ints, slices, Ellipsis, None); "
-                                  "index on a CpuTensor and move the result with .hip()")
+    if any(_is_advanced(i) for i in idx):
+        raise NotImplementedError("integer-array indices go through _take_plan")
     n_real = _py.sum(1 for i in idx if i is not None and i is not Ellipsis)
     if Ellipsis in idx:
         k = idx.index(Ellipsis)
@@ -656,14 +792,25 @@ def _idx_view(a, idx):
 class getitem(Function):
     """ view + dense copy (opencl/ops.py:315-329); backward scatters into zeros (cpu/ops.py:242-246) """
     def forward(ctx, a, idx):
-        ctx.save_for_backward(a._shape, idx)
-        if isinstance(idx, HipTensor):
+        if isinstance(idx, HipTensor) and a._dtype == _F32 and idx._dtype in (np.dtype(np.int32), np.dtype(np.int64)):
             # integer tensor index on the first axis = embedding lookup (examples/bert.py:19-21 does it on the CPU)
+            ctx.save_for_backward(a._shape, idx)
             return _gather_rows(a, idx)
+        plan = _take_plan(a, idx)
+        if plan is not None:
+            # integer-array index on one axis / the (range, labels) pair: gather forward, scatter-add backward (csrc/index.hip)
+            ctx.save_for_backward(a._shape, plan)
+            return _take(a, plan)
+        ctx.save_for_backward(a._shape, idx)
         return _idx_view(a, idx).copy()
 
     def backward(ctx, out_grad):
         shape, idx = ctx.get_saved_tensors()
+        if isinstance(idx, _TakePlan):
+            _require_f32(out_grad)
+            grad = HipTensor.zeros(shape, requires_grad=False)
+            _scatter_add(grad, idx, out_grad)
+            return grad
         if isinstance(idx, HipTensor):
             # repeated ids accumulate.  A leaf table that already owns a gradient buffer (an embedding matrix after
             # zero_grad) gets the rows added in place: no table-sized zero fill, no table-sized `grad +=`
@@ -686,6 +833,10 @@ class setitem(Function):
     """ strided copy / fill into the indexed view (opencl/ops.py:331-340) """
     def forward(ctx, a, idx, val):
         flush_lazy_readers(a)
+        plan = _take_plan(a, idx)
+        if plan is not None:
+            _put(a, plan, val)
+            return a
         view = _idx_view(a, idx)
         if isinstance(val, np.ndarray) and val.ndim > 0:
             val = HipTensor.from_numpy(val.astype(a._dtype), requires_grad=False)

@@ -21,7 +21,17 @@ struct Runtime {
     // arrives last at a tile folds the partial products and resets the counter
     int*        gemm_tickets = nullptr;
     int         n_gemm_tickets = 0;
+    // device status flag: one int in pinned, device-mapped host memory.  Kernels that meet an index / label out of
+    // range OR a bit into it (system scope); lg_sync / lg_memcpy_d2h read it from the host side after their stream
+    // synchronisation and report LG_EINDEX once.
+    int*        status_host = nullptr;
+    int*        status_dev = nullptr;
 };
+
+constexpr int LG_STATUS_BAD_INDEX = 1;
+
+// after a stream synchronisation: turn a raised status flag into an error (and clear it)
+int check_device_status(const char* who);
 Runtime& rt();
 
 // true between lg_graph_begin and lg_graph_end

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) layernorm_param_grads(const float* __rest
 template <typename LabelT>
 __global__ void __launch_bounds__(256) cross_entropy_rows(const float* __restrict__ x, const LabelT* __restrict__ labels,
                                                           float* __restrict__ dlogits, float* __restrict__ nll, int64_t rows,
-                                                          int64_t cols, float inv_rows) {
+                                                          int64_t cols, float inv_rows, int* status) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -222,6 +222,9 @@ __global__ void __launch_bounds__(256) cross_entropy_rows(const float* __restric
     const float inv = 1.0f / s;
     int64_t label = int64_t(labels[row]);
     if (label < 0) label += cols;
+    if (label < 0 || label >= cols) {                 // the reference raises IndexError (loss.py:19); a kernel cannot: NaN + status flag
+        if (lane == 0) { nll[row] = __builtin_nanf(""); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
     for (int64_t c = lane; c < cols; c += 64) {
         const float p = expf(xr[c] + (-m)) * inv;
         dlogits[row * cols + c] = (c == label ? p - 1.0f : p) * inv_rows;
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) cross_entropy_rows(const float* __restric
 template <typename LabelT>
 __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restrict__ x, const LabelT* __restrict__ labels,
                                                           float* __restrict__ dlogits, float* __restrict__ nll, int64_t cols,
-                                                          float inv_rows) {
+                                                          float inv_rows, int* status) {
     __shared__ float red_m[4], red_s[4];
     const int64_t row = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,6 +272,9 @@ __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restric
     const float inv = 1.0f / S;
     int64_t label = int64_t(labels[row]);
     if (label < 0) label += cols;
+    if (label < 0 || label >= cols) {
+        if (threadIdx.x == 0) { nll[row] = __builtin_nanf(""); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
     for (c = threadIdx.x; c < cols; c += 256) {
         const float p = expf(xr[c] + (-M)) * inv;
         dlogits[row * cols + c] = (c == label ? p - 1.0f : p) * inv_rows;
@@ -279,20 +285,23 @@ __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restric
 // ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
 template <typename IdT>
 __global__ void __launch_bounds__(256) gather_rows(const float* __restrict__ table, const IdT* __restrict__ ids, float* __restrict__ out,
-                                                   int64_t n_ids, int64_t row_len, int64_t table_rows) {
+                                                   int64_t n_ids, int64_t row_len, int64_t table_rows, int* status) {
     const int64_t total = n_ids * row_len;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t i = e / row_len, c = e - i * row_len;
         int64_t r = int64_t(ids[i]);
         if (r < 0) r += table_rows;                               // numpy-style negative index
-        out[e] = (r >= 0 && r < table_rows) ? table[r * row_len + c] : __builtin_nanf("");   // host validates; NaN marks a bad id
+        const bool ok = r >= 0 && r < table_rows;
+        if (!ok) __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // NaN + LG_EINDEX at the next sync
+        out[e] = ok ? table[r * row_len + c] : __builtin_nanf("");
     }
 }
 
 template <typename IdT>
 __global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
-                                                        float* __restrict__ grad_table, int64_t n_ids, int64_t row_len, int64_t table_rows) {
+                                                        float* __restrict__ grad_table, int64_t n_ids, int64_t row_len, int64_t table_rows,
+                                                        int* status) {
     const int64_t total = n_ids * row_len;
     const int64_t stride = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -300,6 +309,7 @@ __global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict_
         int64_t r = int64_t(ids[i]);
         if (r < 0) r += table_rows;
         if (r >= 0 && r < table_rows) atomicAdd(grad_table + r * row_len + c, grad_out[e]);   // global_atomic_add_f32, agent scope
+        else __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -365,9 +375,9 @@ extern "C" int lg_gather_rows_f32(const float* table, const void* ids, int id_it
     LG_ARG(table && ids && out, "lg_gather_rows_f32: NULL pointer");
     const unsigned grid = stream_grid(n_ids * row_len);
     if (id_itemsize == 4)
-        hipLaunchKernelGGL(gather_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int32_t*>(ids), out, n_ids, row_len, table_rows);
+        hipLaunchKernelGGL(gather_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int32_t*>(ids), out, n_ids, row_len, table_rows, rt().status_dev);
     else
-        hipLaunchKernelGGL(gather_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int64_t*>(ids), out, n_ids, row_len, table_rows);
+        hipLaunchKernelGGL(gather_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int64_t*>(ids), out, n_ids, row_len, table_rows, rt().status_dev);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
@@ -381,9 +391,9 @@ extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, i
     LG_ARG(grad_out && ids && grad_table, "lg_scatter_add_rows_f32: NULL pointer");
     const unsigned grid = stream_grid(n_ids * row_len);
     if (id_itemsize == 4)
-        hipLaunchKernelGGL(scatter_add_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int32_t*>(ids), grad_table, n_ids, row_len, table_rows);
+        hipLaunchKernelGGL(scatter_add_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int32_t*>(ids), grad_table, n_ids, row_len, table_rows, rt().status_dev);
     else
-        hipLaunchKernelGGL(scatter_add_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int64_t*>(ids), grad_table, n_ids, row_len, table_rows);
+        hipLaunchKernelGGL(scatter_add_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, grad_out, static_cast<const int64_t*>(ids), grad_table, n_ids, row_len, table_rows, rt().status_dev);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
@@ -401,20 +411,20 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     if (cols >= 4096 && rows < (int64_t(1) << 31)) {       // a vocabulary per row: one workgroup per row
         const dim3 wgrid{unsigned(rows)};
         if (label_itemsize == 2)
-            hipLaunchKernelGGL(cross_entropy_wide<int16_t>, wgrid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, cols, inv_rows);
+            hipLaunchKernelGGL(cross_entropy_wide<int16_t>, wgrid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, cols, inv_rows, rt().status_dev);
         else if (label_itemsize == 4)
-            hipLaunchKernelGGL(cross_entropy_wide<int32_t>, wgrid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, cols, inv_rows);
+            hipLaunchKernelGGL(cross_entropy_wide<int32_t>, wgrid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, cols, inv_rows, rt().status_dev);
         else
-            hipLaunchKernelGGL(cross_entropy_wide<int64_t>, wgrid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, cols, inv_rows);
+            hipLaunchKernelGGL(cross_entropy_wide<int64_t>, wgrid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, cols, inv_rows, rt().status_dev);
         LG_CHECK_LAUNCH();
         return LG_OK;
     }
     if (label_itemsize == 2)
-        hipLaunchKernelGGL(cross_entropy_rows<int16_t>, grid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        hipLaunchKernelGGL(cross_entropy_rows<int16_t>, grid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows, rt().status_dev);
     else if (label_itemsize == 4)
-        hipLaunchKernelGGL(cross_entropy_rows<int32_t>, grid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        hipLaunchKernelGGL(cross_entropy_rows<int32_t>, grid, block, 0, s, logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows, rt().status_dev);
     else
-        hipLaunchKernelGGL(cross_entropy_rows<int64_t>, grid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        hipLaunchKernelGGL(cross_entropy_rows<int64_t>, grid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows, rt().status_dev);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

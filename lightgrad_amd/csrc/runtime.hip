@@ -62,6 +62,16 @@ static Pool& pool() {
 
 bool capturing() { return pool().capture != nullptr; }
 
+int check_device_status(const char* who) {
+    Runtime& R = rt();
+    if (R.status_host == nullptr) return LG_OK;
+    const int status = __atomic_exchange_n(R.status_host, 0, __ATOMIC_ACQ_REL);
+    if (status == 0) return LG_OK;
+    set_error("%s: a kernel launched earlier met an index or label outside its axis (device status %d); results of that "
+              "launch hold all-ones bytes / NaN where the index was bad", who, status);
+    return LG_EINDEX;
+}
+
 static size_t round_size(size_t bytes) {
     if (bytes == 0) bytes = 1;
     if (bytes <= (1u << 20)) return (bytes + 511) & ~size_t(511);          // 512 B granules up to 1 MiB
@@ -125,7 +135,10 @@ int lg_init(int device) {
     R.compute_units = prop.multiProcessorCount;
     R.n_gemm_tickets = 1 << 16;
     LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.gemm_tickets), size_t(R.n_gemm_tickets) * sizeof(int)));
-    LG_HIP(hipMemset(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int)));
+    LG_HIP(hipMemsetAsync(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int), R.stream));   // ordered before the first launch
+    LG_HIP(hipHostMalloc(reinterpret_cast<void**>(&R.status_host), 64, hipHostMallocMapped));
+    R.status_host[0] = 0;
+    LG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&R.status_dev), R.status_host, 0));
     R.device = device;
     R.ready = true;
     return LG_OK;
@@ -164,7 +177,7 @@ int lg_sync(void) {
     LG_REQUIRE_INIT();
     LG_ARG(!capturing(), "lg_sync: not allowed while capturing a graph");
     LG_HIP(hipStreamSynchronize(rt().stream));
-    return LG_OK;
+    return check_device_status("lg_sync");
 }
 
 // ---- allocator ---------------------------------------------------------------
@@ -421,7 +434,7 @@ int lg_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     LG_ARG(!capturing(), "lg_memcpy_d2h: host transfers cannot be captured");
     LG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt().stream));
     LG_HIP(hipStreamSynchronize(rt().stream));
-    return LG_OK;
+    return check_device_status("lg_memcpy_d2h");
 }
 
 int lg_memcpy_d2d(void* dst, const void* src, size_t bytes) {

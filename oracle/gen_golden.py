@@ -195,6 +195,58 @@ def main():
         ce[name + "/loss"], ce[name + "/grad"] = np.array(loss.numpy()), np.array(y.grad.numpy())
     np.savez_compressed(os.path.join(OUT, "cross_entropy.npz"), **ce)
 
+    # ---------------------------------------------------------------- fancy indexing: integer index on one
+    # axis, the (arange, labels) pair of loss.cross_entropy (loss.py:19, :22), Dataset batching (data.py:15-32)
+    fi = {}
+    rng4 = np.random.RandomState(4242)
+
+    def run_take(name, shape, index_fn, idx_arrays):
+        a = f32(rng4, -1, 1, shape)
+        t = T.from_numpy(a.copy())
+        y = index_fn(t)
+        w = f32(rng4, -1, 1, y.shape)
+        (y * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        fi[name + "/in"], fi[name + "/out"], fi[name + "/w"], fi[name + "/grad"] = a, np.array(y.numpy()), w, np.array(t.grad.numpy())
+        for k, v in idx_arrays.items():
+            fi["%s/%s" % (name, k)] = v
+    i0 = rng4.permutation(9)[:6].astype(np.int64)
+    run_take("take_axis0", (9, 5), lambda t: t[T.from_numpy(i0, requires_grad=False)], {"idx": i0})
+    i1 = rng4.permutation(7)[:4].astype(np.int32)
+    run_take("take_axis1", (4, 7), lambda t: t[:, T.from_numpy(i1, requires_grad=False)], {"idx": i1})
+    i2 = rng4.permutation(6).reshape(2, 3).astype(np.int64)
+    run_take("take_axis0_2d_index", (6, 3, 4), lambda t: t[T.from_numpy(i2, requires_grad=False)], {"idx": i2})
+    i3 = rng4.permutation(8)[:5].astype(np.int16)
+    run_take("take_middle_axis", (3, 8, 2), lambda t: t[:, T.from_numpy(i3, requires_grad=False), :], {"idx": i3})
+    i4 = np.asarray([-1, 0, -3], np.int64)
+    run_take("take_negative", (5, 4), lambda t: t[T.from_numpy(i4, requires_grad=False)], {"idx": i4})
+    lab = rng4.randint(0, 10, size=8).astype(np.int64)
+    run_take("pair_rows_labels", (8, 10), lambda t: t[range(8), T.from_numpy(lab, requires_grad=False)], {"labels": lab})
+    lab16 = rng4.randint(0, 3, size=5).astype(np.int16)
+    run_take("pair_rows_labels_i16", (5, 3), lambda t: t[range(5), T.from_numpy(lab16, requires_grad=False)], {"labels": lab16})
+    # in-place forms (no gradient): y[range, labels] -= 1 (loss.py:22) and a[idx] = v on one axis
+    a = f32(rng4, -1, 1, (8, 10))
+    t = T.from_numpy(a.copy(), requires_grad=False)
+    with light.no_grad():
+        t[range(8), T.from_numpy(lab, requires_grad=False)] -= 1
+    fi["pair_isub/in"], fi["pair_isub/labels"], fi["pair_isub/out"] = a, lab, np.array(t.numpy())
+    a = f32(rng4, -1, 1, (9, 5))
+    v = f32(rng4, -1, 1, (6, 5))
+    t = T.from_numpy(a.copy(), requires_grad=False)
+    with light.no_grad():
+        t[T.from_numpy(i0, requires_grad=False)] = T.from_numpy(v, requires_grad=False)
+    fi["put_axis0/in"], fi["put_axis0/idx"], fi["put_axis0/val"], fi["put_axis0/out"] = a, i0, v, np.array(t.numpy())
+    # Dataset: shuffle (np.random.permutation -> t[perm]) and batch slices t[i*bs:(i+1)*bs, ...]
+    from lightgrad.data import Dataset as RefDataset
+    X = f32(rng4, 0, 1, (20, 3, 2))
+    Y = rng4.randint(0, 10, size=20).astype(np.int16)
+    np.random.seed(31)
+    ds = RefDataset((T.from_numpy(X, requires_grad=False), T.from_numpy(Y, requires_grad=False)), shuffle=True, batchsize=8)
+    batches = [(np.array(bx.numpy()), np.array(by.numpy())) for bx, by in ds]
+    fi["dataset/X"], fi["dataset/Y"], fi["dataset/seed"], fi["dataset/n_batches"] = X, Y, np.asarray(31), np.asarray(len(batches))
+    for k, (bx, by) in enumerate(batches):
+        fi["dataset/x%d" % k], fi["dataset/y%d" % k] = bx, by
+    np.savez_compressed(os.path.join(OUT, "fancy_index.npz"), **fi)
+
     # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
     # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
     # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.

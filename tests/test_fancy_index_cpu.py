@@ -1,0 +1,83 @@
+"""Integer-array indexing and Dataset batching on the CPU backend against fixtures recorded from the reference
+(tests/golden/fancy_index.npz, written by oracle/gen_golden.py): one index array on any axis, the (range, labels)
+pair of loss.cross_entropy, in-place forms, a seeded Dataset epoch."""
+import numpy as np
+import pytest
+import lightgrad_amd as light
+from lightgrad_amd import CpuTensor
+from conftest import load_golden
+
+TAKE_CASES = {
+    "take_axis0": lambda t, i: t[i], "take_axis1": lambda t, i: t[:, i], "take_axis0_2d_index": lambda t, i: t[i],
+    "take_middle_axis": lambda t, i: t[:, i, :], "take_negative": lambda t, i: t[i],
+}
+PAIR_CASES = ["pair_rows_labels", "pair_rows_labels_i16"]
+
+
+def check_take(cls, g, name, index_fn, key):
+    t = cls.from_numpy(g[name + "/in"].copy())
+    idx = cls.from_numpy(g[name + "/" + key], requires_grad=False)
+    y = index_fn(t, idx)
+    np.testing.assert_array_equal(y.numpy(), g[name + "/out"])                       # index ops are bit-exact
+    (y * cls.from_numpy(g[name + "/w"], requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_array_equal(t.grad.numpy(), g[name + "/grad"])
+    # the same index given as a host array / list
+    y2 = index_fn(cls.from_numpy(g[name + "/in"].copy()), g[name + "/" + key])
+    np.testing.assert_array_equal(y2.numpy(), g[name + "/out"])
+
+
+@pytest.mark.parametrize("name", sorted(TAKE_CASES))
+def test_take_one_axis(name):
+    check_take(CpuTensor, load_golden("fancy_index.npz"), name, TAKE_CASES[name], "idx")
+
+
+@pytest.mark.parametrize("name", PAIR_CASES)
+def test_pair_rows_labels(name):
+    g = load_golden("fancy_index.npz")
+    n = g[name + "/in"].shape[0]
+    check_take(CpuTensor, g, name, lambda t, lab: t[range(n), lab], "labels")
+
+
+def check_inplace(cls, g):
+    t = cls.from_numpy(g["pair_isub/in"].copy(), requires_grad=False)
+    with light.no_grad():
+        t[range(8), cls.from_numpy(g["pair_isub/labels"], requires_grad=False)] -= 1
+    np.testing.assert_array_equal(t.numpy(), g["pair_isub/out"])
+    t = cls.from_numpy(g["put_axis0/in"].copy(), requires_grad=False)
+    with light.no_grad():
+        t[cls.from_numpy(g["put_axis0/idx"], requires_grad=False)] = cls.from_numpy(g["put_axis0/val"], requires_grad=False)
+    np.testing.assert_array_equal(t.numpy(), g["put_axis0/out"])
+
+
+def test_inplace_forms():
+    check_inplace(CpuTensor, load_golden("fancy_index.npz"))
+
+
+def check_dataset(cls, g):
+    np.random.seed(int(g["dataset/seed"]))
+    ds = light.data.Dataset((cls.from_numpy(g["dataset/X"], requires_grad=False), cls.from_numpy(g["dataset/Y"], requires_grad=False)),
+                            shuffle=True, batchsize=8)
+    assert ds.n == 20 and len(ds) == int(g["dataset/n_batches"]) == 3
+    batches = list(ds)
+    assert len(batches) == 3
+    for k, (bx, by) in enumerate(batches):
+        assert isinstance(bx, cls) and isinstance(by, cls) and by.dtype == np.int16
+        np.testing.assert_array_equal(bx.numpy(), g["dataset/x%d" % k])
+        np.testing.assert_array_equal(by.numpy(), g["dataset/y%d" % k])
+    assert batches[-1][0].shape == (4, 3, 2)                                          # ragged last batch
+    # no shuffling: batches are plain slices
+    plain = light.data.Dataset((cls.from_numpy(g["dataset/X"], requires_grad=False),), shuffle=False, batchsize=7)
+    np.testing.assert_array_equal(np.concatenate([b[0].numpy() for b in plain]), g["dataset/X"])
+
+
+def test_dataset_epoch_matches_reference():
+    check_dataset(CpuTensor, load_golden("fancy_index.npz"))
+
+
+def test_repeated_indices_accumulate_in_backward():
+    """documented divergence: the reference's `grad[idx] = out_grad` (cpu/ops.py:245) keeps the LAST of repeated rows;
+    the gradient of a gather sums them (embedding semantics)"""
+    t = CpuTensor.from_numpy(np.zeros((4, 2), np.float32))
+    y = t[np.asarray([1, 1, 3])]
+    (y * CpuTensor.from_numpy(np.asarray([[1, 2], [10, 20], [5, 5]], np.float32), requires_grad=False)).backward(allow_fill=True)
+    np.testing.assert_array_equal(t.grad.numpy(), [[0, 0], [11, 22], [0, 0], [5, 5]])

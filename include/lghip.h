@@ -263,7 +263,7 @@ int lg_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n
                          const int64_t* step, int64_t t_mul, int64_t t_add, double gscale, int belief);
 int lg_counter_add_i64(int64_t* counter, int64_t delta);
 
-/* All parameters of a model in one launch: p, g, m, v are flat buckets holding `nseg` (<= 64) parameters
+/* All parameters of a model in one launch (groups of 64 parameters per launch beyond that): p, g, m, v are flat buckets holding `nseg` parameters
  * back to back, parameter j occupying [offsets[j], offsets[j+1]); its step number is
  * t = step[0] * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32.  `step` points at TWO int64:
  * step[0] the optimizer step, step[1] an arrival ticket that must be 0 between launches; with advance != 0

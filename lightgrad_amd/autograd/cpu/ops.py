@@ -314,7 +314,7 @@ class getitem(Function):
 
     def backward(ctx, out_grad):
         shape, idx = ctx.get_saved_tensors()
-        grad = np.zeros(shape, dtype=np.float32)
+        grad = np.zeros(shape, dtype=CpuTensor.default_dtype)
         parts = idx if isinstance(idx, tuple) else (idx,)
         if any(isinstance(i, (list, range)) or (isinstance(i, np.ndarray) and i.dtype.kind in "iu") for i in parts):
             # integer-array (embedding) index: repeated ids must ACCUMULATE.  The reference's `grad[idx] = out_grad`
@@ -430,7 +430,7 @@ class conv(Function):
         g2 = np.moveaxis(out_grad, -n, -1).reshape(-1, k_shape[0])
         dw = (g2.T @ cols).reshape(k_shape)
         dwin = (g2 @ w2).reshape(win_shape)
-        dx = np.zeros(in_shape, dtype=np.float32)
+        dx = np.zeros(in_shape, dtype=CpuTensor.default_dtype)
         lead = len(in_shape) - n
         out_pos = win_shape[lead:lead + n]
         # every window offset contributes one strided slab of the input gradient (slabs of one offset never overlap)

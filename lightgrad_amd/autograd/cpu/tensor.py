@@ -22,8 +22,12 @@ def _payload(source, dtype) -> np.ndarray:
 
 class CpuTensor(AbstractTensor):
 
-    def __init__(self, data, dtype: type = np.float32, requires_grad: bool = True) -> None:
-        AbstractTensor.__init__(self, data=_payload(data, dtype), requires_grad=requires_grad)
+    # float32 like the reference.  Tests switch it to float64 to obtain a higher-precision run of the SAME tape (every
+    # initialiser, gradient seed and gradient copy then stays in double) - the yardstick fp32 results are measured against
+    default_dtype = np.float32
+
+    def __init__(self, data, dtype: type = None, requires_grad: bool = True) -> None:
+        AbstractTensor.__init__(self, data=_payload(data, CpuTensor.default_dtype if dtype is None else dtype), requires_grad=requires_grad)
 
     dtype = property(lambda self: self.data.dtype)
     shape = property(lambda self: self.data.shape)

@@ -133,7 +133,9 @@ namespace lg {
 
 constexpr int kMaxSegments = 64;
 struct AdamSegments {
-    int     nseg;
+    int     nseg;          // parameters in THIS launch (<= kMaxSegments)
+    int     nseg_total;    // parameters of the optimizer: the reference's `t` advances once per parameter (optim.py:36/:48)
+    int     first;         // index of this launch's first parameter
     int64_t offsets[kMaxSegments + 1];
 };
 
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
     if (first < n) {                                   // workgroup-uniform
         if (threadIdx.x == 0) {
             // the two double-precision powers once per workgroup, not once per thread (they were most of the kernel)
-            const double t = double(step[0] * seg.nseg + j + 1);
+            const double t = double(step[0] * seg.nseg_total + seg.first + j + 1);
             inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
             inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
         }
@@ -197,14 +199,36 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
 
 }  // namespace lg
 
+static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets, int first, int nseg_total,
+                               double lr, double b1, double b2, double eps, int64_t* step, double gscale, int belief, int advance);
+
 extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
                                      double lr, double b1, double b2, double eps, int64_t* step, double gscale,
                                      int belief, int advance) {
     LG_REQUIRE_INIT();
-    LG_ARG(nseg >= 1 && nseg <= kMaxSegments, "lg_adam_multi_dev_f32: %d segments (1..%d supported)", nseg, kMaxSegments);
+    LG_ARG(nseg >= 1, "lg_adam_multi_dev_f32: %d segments", nseg);
     LG_ARG(p && g && m && v && step && offsets, "lg_adam_multi_dev_f32: NULL pointer");
+    if (nseg > kMaxSegments) {
+        // more parameters than one launch's argument block holds (tiny-BERT has 40+, larger models hundreds): groups of
+        // kMaxSegments, one launch each.  Every group reads the same step[0]; with the ticket form the LAST group alone
+        // advances it (stream order: the earlier groups have finished reading by then).
+        for (int first = 0; first < nseg; first += kMaxSegments) {
+            const int count = nseg - first < kMaxSegments ? nseg - first : kMaxSegments;
+            const int rc = lg_adam_multi_group(p, g, m, v, count, offsets + first, first, nseg, lr, b1, b2, eps, step, gscale, belief,
+                                               (advance && first + count == nseg) ? 1 : 0);
+            if (rc != LG_OK) return rc;
+        }
+        return LG_OK;
+    }
+    return lg_adam_multi_group(p, g, m, v, nseg, offsets, 0, nseg, lr, b1, b2, eps, step, gscale, belief, advance);
+}
+
+static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets, int first, int nseg_total,
+                               double lr, double b1, double b2, double eps, int64_t* step, double gscale, int belief, int advance) {
     AdamSegments seg;
     seg.nseg = nseg;
+    seg.nseg_total = nseg_total;
+    seg.first = first;
     int64_t longest = 0;
     for (int j = 0; j <= nseg; ++j) {
         seg.offsets[j] = offsets[j];

@@ -75,7 +75,19 @@ __global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, 
     }
 }
 
-// dx = y * (g - sum(g * y))
+// dx = y * (g - sum(g * y) / sum(y)).  The shift sum(g*y) is formed, divided by sum(y) (1 up to the rounding of y) and
+// subtracted in DOUBLE: every row of dx must sum to zero, and consumers rely on it - the query / key gradients of
+// attention are d(scores) @ k and d(scores)^T @ q with k, q nearly constant along the summed axis at initialisation, a
+// contraction that cancels everything EXCEPT the row sums of d(scores) (condition ~150 on tiny-BERT).  With an fp32 shift
+// every element of a row carries the same error eps*|shift| (|shift| ~ 30 |dx| there): measured against a float64 run of the
+// tape the query-weight gradient was 3.3e-4 off, the fp32 CPU backend 9e-6 (tools/bert_grad_probe.py); with the double shift
+// the error left is eps*|dx| per element.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ void __launch_bounds__(256) softmax_bwd(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ dx,
                                                    int64_t rows, int64_t cols) {
     const int lane = threadIdx.x & 63;
@@ -84,10 +96,12 @@ __global__ void __launch_bounds__(256) softmax_bwd(const float* __restrict__ y, 
     const float* yr = y + row * cols;
     const float* gr = g + row * cols;
     float* dr = dx + row * cols;
-    float dot = 0.f;
-    for (int64_t c = lane; c < cols; c += 64) dot += gr[c] * yr[c];
-    dot = wave_sum(dot);
-    for (int64_t c = lane; c < cols; c += 64) dr[c] = yr[c] * (gr[c] - dot);
+    double dot = 0.0, norm = 0.0;
+    for (int64_t c = lane; c < cols; c += 64) { const double yc = double(yr[c]); dot += double(gr[c]) * yc; norm += yc; }
+    dot = wave_sum_f64(dot);
+    norm = wave_sum_f64(norm);
+    const double shift = dot / norm;
+    for (int64_t c = lane; c < cols; c += 64) dr[c] = float(double(yr[c]) * (double(gr[c]) - shift));
 }
 
 // ---- LayerNorm over the last axis ---------------------------------------------------------------------

@@ -25,8 +25,14 @@ def test_forward_matches_reference_fixture(hip):
     assert (logits.argmax(-1) == g["argmax"]).mean() > 0.995
 
 
-def test_forward_backward_matches_cpu_backend(hip):
-    """full tiny config, batch 2: every parameter gradient of a scalar objective, HIP vs CPU"""
+def test_forward_backward_matches_cpu_backend(hip, monkeypatch):
+    """full tiny config, batch 2: every parameter gradient of a scalar objective, measured against a FLOAT64 run of the same
+    tape on the same parameter values (CpuTensor.default_dtype = float64) - the reference has no working BERT backward
+    (SURVEY.md 3.4), so the yardstick is exact arithmetic, not another fp32 result.  Every HIP gradient must be within the
+    north-star 1e-5 (relative Frobenius).  The query / key gradients are the hard ones: ~1e-7 in norm, the outcome of a
+    contraction that cancels all of d(scores) but its row sums (condition ~150); round 1 accepted 5e-3 for them "because of
+    cancellation" - the float64 yardstick showed the fp32 CPU backend at 1e-5 and HIP at 3e-4, i.e. a weakness of the
+    fused softmax backward (an fp32 shift common to a row), fixed there (csrc/rowwise.hip) - now 5e-6."""
     g = load_golden("bert_tiny_forward.npz")
     cpu_model = build_tiny()
     hip_model = build_tiny().map_parameters(lambda p: p.hip())
@@ -35,16 +41,35 @@ def test_forward_backward_matches_cpu_backend(hip):
     for model, T in ((cpu_model, CpuTensor), (hip_model, hip)):
         logits = model(T.from_numpy(g["ids"], requires_grad=False))
         (logits * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
-    for (n, p), (_, q) in zip(cpu_model.named_parameters(), hip_model.named_parameters()):
-        ref, got = p.grad.numpy().astype(np.float64), q.grad.numpy().astype(np.float64)
+    values = {n: p.numpy().astype(np.float64) for n, p in cpu_model.named_parameters()}
+    monkeypatch.setattr(CpuTensor, "default_dtype", np.float64)
+    ref_model = build_tiny()
+    ref_model.load_parameters(values)
+    assert all(p.dtype == np.float64 for p in ref_model.parameters())
+    logits = ref_model(CpuTensor.from_numpy(g["ids"], requires_grad=False))
+    assert logits.dtype == np.float64
+    (logits * CpuTensor.from_numpy(w.astype(np.float64), requires_grad=False)).backward(allow_fill=True)
+    monkeypatch.undo()
+    report = []
+    for (n, p), (_, q), (_, r) in zip(cpu_model.named_parameters(), hip_model.named_parameters(), ref_model.named_parameters()):
+        assert r.grad.dtype == np.float64
+        ref, cpu, got = r.grad.numpy(), p.grad.numpy().astype(np.float64), q.grad.numpy().astype(np.float64)
         if ".key.bias" in n:
-            # mathematically zero (softmax is invariant to a per-query constant): both sides are rounding noise
-            assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6, (n, np.abs(got).max(), np.abs(ref).max())
+            # mathematically zero (softmax is invariant to a per-query constant): all three are rounding noise
+            assert np.abs(got).max() < 1e-6 and np.abs(cpu).max() < 1e-6 and np.abs(ref).max() < 1e-12, (n, np.abs(got).max(), np.abs(ref).max())
             continue
-        rel = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300)
-        # query/key gradients of a randomly initialised model are ~1e-8: pure cancellation through an almost uniform
-        # softmax, so fp32 summation order shows up at the 1e-3 level; everything else agrees to ~1e-5
-        assert rel <= (5e-3 if (".query." in n or ".key." in n) else 2e-4), (n, rel)
+        scale = np.linalg.norm(ref) + 1e-300
+        e_cpu, e_hip = np.linalg.norm(cpu - ref) / scale, np.linalg.norm(got - ref) / scale
+        report.append((n, scale, e_cpu, e_hip))
+        assert e_hip <= 1e-5, (n, "HIP vs float64: %.2e (fp32 CPU backend vs float64: %.2e)" % (e_hip, e_cpu))
+        assert e_cpu <= 5e-5, (n, "fp32 CPU backend vs float64: %.2e" % e_cpu)
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "bert_grad_errors.txt"), "w") as f:
+            f.write("parameter | ||grad|| (float64) | fp32 CPU backend vs float64 | HIP vs float64 (relative Frobenius)\n")
+            for n, sc, ec, eh in report:
+                f.write("%-70s %.3e  %.2e  %.2e\n" % (n, sc, ec, eh))
 
 
 def test_small_model_gradcheck(hip):

@@ -303,3 +303,35 @@ def test_lazy_relu_is_a_snapshot_of_its_source(hip):
     opt.step()
     np.testing.assert_array_equal(r.numpy(), want)
     assert np.abs(w.numpy() - base).max() > 1e-3
+
+
+def test_multi_tensor_adam_beyond_64_parameters(hip):
+    """the flat-bucket optimizer launch takes 64 parameters per launch; a model with more (tiny-BERT has 40+, anything
+    bigger hundreds) goes in groups - every parameter must still see its own step number t = step * P + j + 1 (the
+    reference's per-parameter `t`, optim.py:36/:48).  Pinned bit for bit against the one-parameter kernel."""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(12)
+    sizes = [int(v) for v in rng.randint(1, 40, 150)]
+    offsets = tuple(int(o) for o in np.concatenate([[0], np.cumsum(sizes)]))
+    total = offsets[-1]
+    p0, g0 = rng.uniform(-1, 1, total).astype(np.float32), rng.uniform(-1, 1, total).astype(np.float32)
+    results = []
+    for flat in (True, False):
+        p, g = hip.from_numpy(p0.copy(), requires_grad=False), hip.from_numpy(g0.copy(), requires_grad=False)
+        m, v = hip.zeros((total,), requires_grad=False), hip.zeros((total,), requires_grad=False)
+        counter = hip.from_numpy(np.asarray([3, 0], np.int64), requires_grad=False)
+        for _ in range(2):
+            if flat:
+                L.check(lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, len(sizes), L.i64(offsets), 1e-2, 0.9, 0.999, 1e-8,
+                                                  counter.ptr, 0.5, 1, 0))
+            else:
+                for j, n in enumerate(sizes):
+                    o = offsets[j] * 4
+                    L.check(lib.lg_adam_step_dev_f32(p.ptr + o, g.ptr + o, m.ptr + o, v.ptr + o, n, 1e-2, 0.9, 0.999, 1e-8,
+                                                     counter.ptr, len(sizes), j + 1, 0.5, 1))
+            L.check(lib.lg_counter_add_i64(counter.ptr, 1))
+        results.append((p.numpy(), m.numpy(), v.numpy()))
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(results[0][0] - p0).max() > 1e-3

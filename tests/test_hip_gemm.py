@@ -155,6 +155,27 @@ def test_4096_forward_backward_properties(hip):
     np.testing.assert_array_equal(y2, 2 * yn)
 
 
+def test_4096_forward_backward_whole_matrices_vs_float64(hip):
+    """BASELINE config #2 at full size, no sampling: the WHOLE of y = A @ B, dA = W @ B^T and dB = A^T @ W (random upstream
+    gradient W) against float64 numpy - relative Frobenius error <= 1e-5 (north-star tolerance), and element-wise within
+    the fp32 forward-error bound"""
+    n = 4096
+    rng = np.random.RandomState(5)
+    a = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    w = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    ta, tb = hip.from_numpy(a), hip.from_numpy(b)
+    y = ta @ tb
+    (y * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    a64, b64, w64 = a.astype(np.float64), b.astype(np.float64), w.astype(np.float64)
+    for got, ref in ((y.numpy(), a64 @ b64), (ta.grad.numpy(), w64 @ b64.T), (tb.grad.numpy(), a64.T @ w64)):
+        assert rel_err(got, ref) <= 1e-5
+        # |error| of an fp32 dot product of length 4096 with |terms| <= 1: far below 4096 * 2^-24 * sqrt-ish growth; a wrong
+        # tile, a dropped K-slice or a misplaced row would be O(1)
+        assert np.abs(got - ref).max() <= 2e-3
+    del a64, b64, w64
+
+
 @pytest.mark.parametrize("mkn", [(512, 1024, 784), (10, 1024, 512), (64, 64, 64), (64, 100, 128), (33, 31, 35), (130, 700, 63),
                                  (1, 5, 1), (200, 36, 300), (128, 2048, 128), (7, 3, 2), (256, 512, 255)])
 def test_rowsum_column_of_the_product(hip, mkn):

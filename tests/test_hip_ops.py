@@ -158,8 +158,9 @@ def test_views_and_indexing(hip):
     t[:, 2, :] = hip.from_numpy(a[0, 0])                           # broadcast row
     b[:, 2, :] = a[0, 0]
     np.testing.assert_array_equal(t.numpy(), b)
+    np.testing.assert_array_equal(t[[0, 1]].numpy(), b[[0, 1]])      # integer-array index: device gather (tests/test_hip_index.py)
     with pytest.raises(NotImplementedError):
-        t[[0, 1]]
+        t[[0, 1], [1, 2], [0, 0]]                                  # three index arrays: not on the device
     with pytest.raises(IndexError):
         t[6]
 

@@ -125,7 +125,9 @@ def test_c_abi_argument_checks(hip):
     assert lib.lg_copy_strided(3, 2, sh, t.ptr, st, t.ptr, st) == -1                                              # itemsize 3
     assert lib.lg_softmax_f32(t.ptr, t.ptr, 4, 0) == -1
     assert lib.lg_gather_rows_f32(t.ptr, t.ptr, 2, t.ptr, 1, 4, 4) == -1                                          # int16 ids
-    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 65, L.i64((0,) * 66), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == -1
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 0, L.i64((0,)), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == -1        # no segments
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 65, L.i64((0,) * 66), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == 0    # 65 EMPTY segments: two groups, nothing to do
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 2, L.i64((0, 8, 4)), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == -1    # decreasing offsets
     ev = ctypes.c_void_p()
     assert lib.lg_event_create(ctypes.byref(ev)) == 0 and lib.lg_event_record(ev) == 0 and lib.lg_event_destroy(ev) == 0
     np.testing.assert_array_equal(t.numpy(), np.zeros((4, 4), np.float32))                                        # nothing was written

@@ -34,7 +34,7 @@ with g.capture():
     out = body()
 for i in range(replays):
     g.replay()
-    if (i + 1) % 100 == 0:
+    if (i + 1) % 100 == 0 or kernels >= 100:
         HipDevice.synchronize()
         print("replay %d  (~%d kernel packets submitted)" % (i + 1, (i + 1) * kernels), flush=True)
 HipDevice.synchronize()

@@ -10,7 +10,8 @@ newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)   # gpuru
 shutil.copy(newest(src + "/stats/*/*_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats_%s.csv" % tag))
 shutil.copy(os.path.join(src, "mlp_step_trace.txt"), os.path.join(dst, "mlp_step_trace_%s.txt" % tag))
 shutil.copy(os.path.join(src, "gemm_sweep.txt"), os.path.join(dst, "gemm_sweep_%s.txt" % tag))
-for extra in ("hbm_bench", "mlp_gemm_bench"):
+for extra in ("hbm_bench", "mlp_gemm_bench", "head_bench", "gemm_timeline", "pmc_sq_mlp_gemm", "step_gap_one_step_per_graph",
+              "step_gap_eight_steps_per_graph", "wrap_summary"):
     if os.path.exists(os.path.join(src, extra + ".txt")):
         shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
 pmc = {}
@@ -32,5 +33,13 @@ json.dump({"sgemm_mfma_256x256_NN_4096": {
     "source": "profiles/%s/pmc_fetch_size_%s.csv, pmc_write_size_%s.csv (rocprofv3 --pmc, one counter per pass, tools/profile_kernels.py)" % (rnd, tag, tag)}},
     open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 d = json.load(open(os.path.join(src, "bench.json")))
+for f in glob.glob(src + "/wrap_rocprof_*.log"):           # the profiler-side fault: keep the head of every log (banner, progress, backtrace)
+    with open(f, errors="replace") as fh:
+        lines = fh.read().splitlines()
+    keep = [l for l in lines if "replay" in l or "done" in l or "SIGSEGV" in l or "PC:" in l or l.strip().startswith("@")]
+    with open(os.path.join(dst, os.path.basename(f).replace(".log", "_%s.txt" % tag)), "w") as fh:
+        fh.write("\n".join(keep[-40:]) + "\n")
+if os.path.exists("gpurun_out/bert_grad_errors.txt"):
+    shutil.copy("gpurun_out/bert_grad_errors.txt", os.path.join(dst, "bert_grad_errors_%s.txt" % tag))
 print(json.dumps({k: d[k] for k in ("value", "ms_per_step", "secondary", "roofline", "tiny_bert_fwd_bwd", "cpu_baseline")}, indent=0)[:2500])
-print({k: v["GB/s"] for k, v in d["roofline_hbm"].items()})
+print({k: v["GB/s"] for k, v in d["roofline_hbm"].items() if isinstance(v, dict)})

@@ -1,13 +1,51 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: produces everything profiles/README.md cites under gpurun_out/final/.
+# Every step has its own limit; a step killed at its limit stops the script (never start another GPU step after a hang).
 export TMPDIR=/tmp
 out=gpurun_out/final
 rm -rf $out; mkdir -p $out
-timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err; echo "stats rc=$?"
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 tools/profile_kernels.py > $out/fetch.log 2>&1; echo "fetch rc=$?"
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 tools/profile_kernels.py > $out/write.log 2>&1; echo "write rc=$?"
+step() {   # step <name> <seconds> <command...>   (stdout -> $out/<name>.out unless the command redirects)
+  local name=$1 secs=$2; shift 2
+  timeout -k 10 "$secs" bash -c "$*" ; local rc=$?
+  echo "[$name] rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed at its limit: stopping"; exit $rc; fi
+}
+step bench 400 "python bench.py > $out/bench.json 2> $out/bench.err"
+step stats 400 "rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 200 --warmup 10 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err"
+step fetch 200 "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 tools/profile_kernels.py > $out/fetch.log 2>&1"
+step write 200 "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 tools/profile_kernels.py > $out/write.log 2>&1"
+step trace1 200 "rocprofv3 --kernel-trace --output-format csv -d $out/trace1 -- python3 bench.py --steps 200 --warmup 10 --no-extras --graph-steps 1 > $out/bench_one_step_per_graph.json 2> $out/trace1.err"
 python tools/step_trace.py $out/stats/*/*_kernel_trace.csv > $out/mlp_step_trace.txt; tail -1 $out/mlp_step_trace.txt
-for n in 1024 2048 3072 4096 8192; do timeout -k 5 100 python tools/gemm_bench.py $n 3; done > $out/gemm_sweep.txt 2>&1; cat $out/gemm_sweep.txt
-timeout -k 10 200 python tools/hbm_bench.py > $out/hbm_bench.txt 2>&1; tail -3 $out/hbm_bench.txt
-timeout -k 10 100 python tools/mlp_gemm_bench.py > $out/mlp_gemm_bench.txt 2>&1; cat $out/mlp_gemm_bench.txt
+python tools/step_gap.py $out/trace1/*/*_kernel_trace.csv > $out/step_gap_one_step_per_graph.txt; cat $out/step_gap_one_step_per_graph.txt
+python tools/step_gap.py $out/stats/*/*_kernel_trace.csv > $out/step_gap_eight_steps_per_graph.txt; cat $out/step_gap_eight_steps_per_graph.txt
+step sweep 300 "for n in 1024 2048 3072 4096 8192; do python tools/gemm_bench.py \$n 3; done > $out/gemm_sweep.txt 2>&1"; cat $out/gemm_sweep.txt
+step hbm 200 "python tools/hbm_bench.py > $out/hbm_bench.txt 2>&1"; tail -3 $out/hbm_bench.txt
+step mlpgemm 100 "python tools/mlp_gemm_bench.py > $out/mlp_gemm_bench.txt 2>&1"; cat $out/mlp_gemm_bench.txt
+step headbench 100 "python tools/head_bench.py > $out/head_bench.txt 2>&1"; cat $out/head_bench.txt
+step timeline 100 "python tools/gemm_timeline.py > $out/gemm_timeline.txt 2>&1"; tail -3 $out/gemm_timeline.txt
+# SQ counters of the six MLP GEMM shapes + the head kernels (one counter pair per pass)
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  step sq$i 200 "rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/sq$i -- python3 tools/mlp_gemm_bench.py > $out/sq$i.log 2>&1"
+done
+python3 - <<'PY' > gpurun_out/final/pmc_sq_mlp_gemm.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/final/sq*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "sgemm" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"][:64], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for (k, grid), cs in sorted(agg.items()):
+    print("%s  grid=%s" % (k, grid))
+    for c, v in sorted(cs.items()):
+        print("    %-28s %16.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY
+cat $out/pmc_sq_mlp_gemm.txt | head -60
+# the rocprofv3 fault at the first wrap of the 16384-packet AQL ring, by graph size (profiles/README.md r2)
+for spec in "10 2000" "50 400" "200 100" "400 50"; do
+  set -- $spec
+  step wrap_plain_$1 100 "python tools/graph_wrap_probe.py $1 $2 > $out/wrap_plain_$1.log 2>&1"
+  ( cd /tmp && timeout -k 10 150 rocprofv3 --kernel-trace -d /tmp/wrap_$1 -- python3 $GRAFT_REPO_ROOT/tools/graph_wrap_probe.py $1 $2 > $GRAFT_REPO_ROOT/$out/wrap_rocprof_$1.log 2>&1; echo "[wrap_rocprof_$1] rc=$?" )
+done
+for f in $out/wrap_*.log; do echo "$f: $(grep -c SIGSEGV $f) SIGSEGV, last line: $(grep 'replay\|done' $f | tail -1)"; done | tee $out/wrap_summary.txt

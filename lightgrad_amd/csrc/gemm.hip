@@ -111,18 +111,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // the 256x256 tile never splits K (its launches have >= 256 tiles or lose to smaller tiles in the cost model); leaving
 // the fold out of that instantiation keeps its main loop free of spills
-template <int BM, int BN> constexpr bool kCanSplitK = BM * BN < 256 * 256;
+template <int BM, int BN> constexpr bool kHasExtras = BM * BN < 256 * 256;      // relu operands, row sums: small tiles only
+template <int BM, int BN, int KG = 1> constexpr bool kCanSplitK = kHasExtras<BM, BN> && KG == 1;
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD>
-__global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
-    constexpr int NT = WM * WN * 64;
+// KG = 2: "K-groups" - the split of K happens INSIDE the workgroup.  Twice the waves on the same BM x BN tile; a K-step stages
+// BK*KG k-values, wave group g multiplies k in [g*BK, (g+1)*BK) of it, and after the loop group 1 hands its accumulators to
+// group 0 through LDS.  For outputs with too few 64x64 tiles to fill the chip this replaces the cross-workgroup split-K (slab
+// write + drain + ticket + fold = 2.6 us of a 14.6 us launch, profiles/r2/gemm_timeline_v1.txt) by one LDS exchange: a 64x32
+// tile with 2 x 2 waves does per wave exactly the MFMA work of a 64x64 tile with 2 K-slices, one workgroup per CU.
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
+__global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
+    constexpr int NT = WM * WN * KG * 64;
+    constexpr int BKS = BK * KG;                         // k-values staged per K-step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(TM >= 1 && TN >= 1 && BK % 16 == 0, "tile config");
-    constexpr int A_PITCH = AKC ? BK + 4 : BM;          // floats per LDS row
-    constexpr int B_PITCH = BKC ? BK + 4 : BN;
-    constexpr int A_TILE = AKC ? BM * A_PITCH : BK * A_PITCH;
-    constexpr int B_TILE = BKC ? BN * B_PITCH : BK * B_PITCH;
-    constexpr int A_ELEMS = BM * BK / NT, B_ELEMS = BN * BK / NT;   // floats staged per thread
+    static_assert(TM >= 1 && TN >= 1 && BK % 16 == 0 && (KG == 1 || KG == 2), "tile config");
+    constexpr int A_PITCH = AKC ? BKS + 4 : BM;          // floats per LDS row
+    constexpr int B_PITCH = BKC ? BKS + 4 : BN;
+    constexpr int A_TILE = AKC ? BM * A_PITCH : BKS * A_PITCH;
+    constexpr int B_TILE = BKC ? BN * B_PITCH : BKS * B_PITCH;
+    constexpr int A_ELEMS = BM * BKS / NT, B_ELEMS = BN * BKS / NT;   // floats staged per thread
     static_assert(A_ELEMS % 4 == 0 && B_ELEMS % 4 == 0, "staging must divide into float4");
 
     __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
@@ -131,7 +138,9 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int kg = wave / (WM * WN), wl = wave % (WM * WN);          // K-group of this wave, wave inside the group
+    const int wm = wl / WN, wn = wl % WN;
+    const int kofs = kg * BK;                                        // its k offset inside a staged K-step
     const int r = lane & 31, h = lane >> 5;
     LG_TL(0);                                        // workgroup entered
 
@@ -163,7 +172,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     const int64_t k_begin = int64_t(slice) * g.k_per_slice;
     const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
     // the virtual ones-column (row sums of A) lives in column N of this workgroup's tile, if at all
-    const bool has_virtual = kCanSplitK<BM, BN> && g.rowsum != nullptr && n0 <= g.N && g.N < n0 + BN;
+    const bool has_virtual = kHasExtras<BM, BN> && g.rowsum != nullptr && n0 <= g.N && g.N < n0 + BN;
 
     // staging registers: a ring of PD K-tiles in flight between global memory and LDS (PD = 1: the tile fetched at the
     // top of an iteration is written to LDS in its middle; small tiles have too few MFMAs per K-tile to cover the
@@ -189,8 +198,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     for (int i = 0; i < A_CHUNKS; ++i) {
         const int f = tid + i * NT;
         int row, kk;                                  // row: index along M inside the tile, kk: index along K
-        if constexpr (VA) { if constexpr (AKC) { row = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BM / 4); row = (f % (BM / 4)) * 4; } }
-        else              { if constexpr (AKC) { row = f / BK; kk = f % BK; } else { kk = f / BM; row = f % BM; } }
+        if constexpr (VA) { if constexpr (AKC) { row = f / (BKS / 4); kk = (f % (BKS / 4)) * 4; } else { kk = f / (BM / 4); row = (f % (BM / 4)) * 4; } }
+        else              { if constexpr (AKC) { row = f / BKS; kk = f % BKS; } else { kk = f / BM; row = f % BM; } }
         kcA[i] = kk;
         // 32-bit on purpose: the host guarantees that a tile's farthest byte offset is below 2^31
         const unsigned bytes = AKC ? (unsigned(row) * unsigned(g.lda) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.lda) + unsigned(row)) * 4u;
@@ -200,8 +209,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     for (int i = 0; i < B_CHUNKS; ++i) {
         const int f = tid + i * NT;
         int col, kk;
-        if constexpr (VB) { if constexpr (BKC) { col = f / (BK / 4); kk = (f % (BK / 4)) * 4; } else { kk = f / (BN / 4); col = (f % (BN / 4)) * 4; } }
-        else              { if constexpr (BKC) { col = f / BK; kk = f % BK; } else { kk = f / BN; col = f % BN; } }
+        if constexpr (VB) { if constexpr (BKC) { col = f / (BKS / 4); kk = (f % (BKS / 4)) * 4; } else { kk = f / (BN / 4); col = (f % (BN / 4)) * 4; } }
+        else              { if constexpr (BKC) { col = f / BKS; kk = f % BKS; } else { kk = f / BN; col = f % BN; } }
         kcB[i] = kk;
         const unsigned bytes = BKC ? (unsigned(col) * unsigned(g.ldb) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.ldb) + unsigned(col)) * 4u;
         offB[i] = (n0 + col < g.N) ? bytes : OOB;
@@ -223,12 +232,12 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     // the K loop of a lone small-tile workgroup shows up in its time)
     const float* nextA = AKC ? Atile0 + k_begin : Atile0 + k_begin * g.lda;
     const float* nextB = BKC ? Btile0 + k_begin : Btile0 + k_begin * g.ldb;
-    const int64_t stepA = AKC ? int64_t(BK) : int64_t(BK) * g.lda, stepB = BKC ? int64_t(BK) : int64_t(BK) * g.ldb;
-    const int nkt = int((k_end - k_begin + BK - 1) / BK);           // K-tiles of this slice (32-bit: scalar compares in the loop)
-    const int last_krem = int(k_end - k_begin) - (nkt - 1) * BK;     // k values of the last one
+    const int64_t stepA = AKC ? int64_t(BKS) : int64_t(BKS) * g.lda, stepB = BKC ? int64_t(BKS) : int64_t(BKS) * g.ldb;
+    const int nkt = int((k_end - k_begin + BKS - 1) / BKS);         // K-steps of this slice (32-bit: scalar compares in the loop)
+    const int last_krem = int(k_end - k_begin) - (nkt - 1) * BKS;    // k values of the last one
     int requested = 0;
     auto load_tile = [&](int slot) {
-        const int krem = requested == nkt - 1 ? last_krem : BK;      // k values of this tile inside the slice
+        const int krem = requested == nkt - 1 ? last_krem : BKS;     // k values of this tile inside the slice
         ++requested;
         krem_ring[slot] = krem;
         const u32x4 da = descriptor(nextA);
@@ -264,7 +273,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         float* b = lds + buf * BUF + A_TILE;
         // K not a multiple of 4: the last float4 of a K-contiguous row runs into the next row - zero what lies beyond the
         // slice (only the slice's last tile can be short)
-        if (g.k_tail && krem_ring[slot] < BK) {
+        if (g.k_tail && krem_ring[slot] < BKS) {
             asm volatile("; short K tail" ::: "memory");        // keeps this rare fix-up a branch, not selects in every iteration
             if constexpr (VA && AKC) {
 #pragma unroll
@@ -281,7 +290,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                         if (kcB[i] + e >= krem_ring[slot]) rb_ring[slot][i][e] = 0.f;
             }
         }
-        if constexpr (kCanSplitK<BM, BN>) if (g.relu_a) {
+        if constexpr (kHasExtras<BM, BN>) if (g.relu_a) {
             asm volatile("; relu(A) on the way to LDS" ::: "memory");
 #pragma unroll
             for (int i = 0; i < A_CHUNKS; ++i) {
@@ -297,14 +306,14 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int f = tid + i * NT;
             if constexpr (VA) {
-                if constexpr (AKC) *reinterpret_cast<f32x4*>(a + (f / (BK / 4)) * A_PITCH + (f % (BK / 4)) * 4) = ra_ring[slot][i];
+                if constexpr (AKC) *reinterpret_cast<f32x4*>(a + (f / (BKS / 4)) * A_PITCH + (f % (BKS / 4)) * 4) = ra_ring[slot][i];
                 else               *reinterpret_cast<f32x4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = ra_ring[slot][i];
             } else {
-                if constexpr (AKC) a[(f / BK) * A_PITCH + (f % BK)] = ra_ring[slot][i];
+                if constexpr (AKC) a[(f / BKS) * A_PITCH + (f % BKS)] = ra_ring[slot][i];
                 else               a[(f / BM) * A_PITCH + (f % BM)] = ra_ring[slot][i];
             }
         }
-        if constexpr (kCanSplitK<BM, BN>) if (g.relu_b) {
+        if constexpr (kHasExtras<BM, BN>) if (g.relu_b) {
             asm volatile("; relu(B) on the way to LDS" ::: "memory");
 #pragma unroll
             for (int i = 0; i < B_CHUNKS; ++i) {
@@ -316,7 +325,7 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
                 }
             }
         }
-        if constexpr (kCanSplitK<BM, BN>) if (has_virtual) {
+        if constexpr (kHasExtras<BM, BN>) if (has_virtual) {
             // the loads returned zeros for the virtual column (beyond N): put the ones in, for the k values that exist
 #pragma unroll
             for (int i = 0; i < B_CHUNKS; ++i) {
@@ -339,10 +348,10 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         for (int i = 0; i < B_CHUNKS; ++i) {
             const int f = tid + i * NT;
             if constexpr (VB) {
-                if constexpr (BKC) *reinterpret_cast<f32x4*>(b + (f / (BK / 4)) * B_PITCH + (f % (BK / 4)) * 4) = rb_ring[slot][i];
+                if constexpr (BKC) *reinterpret_cast<f32x4*>(b + (f / (BKS / 4)) * B_PITCH + (f % (BKS / 4)) * 4) = rb_ring[slot][i];
                 else               *reinterpret_cast<f32x4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = rb_ring[slot][i];
             } else {
-                if constexpr (BKC) b[(f / BK) * B_PITCH + (f % BK)] = rb_ring[slot][i];
+                if constexpr (BKC) b[(f / BKS) * B_PITCH + (f % BKS)] = rb_ring[slot][i];
                 else               b[(f / BN) * B_PITCH + (f % BN)] = rb_ring[slot][i];
             }
         }
@@ -357,8 +366,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     auto compute_tile = [&](int buf, int kb_begin, int kb_end) {
-        const float* a = lds + buf * BUF + (AKC ? (wm * TM * 32 + r) * A_PITCH + 4 * h : (4 * h) * A_PITCH + wm * TM * 32 + r);
-        const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * TN * 32 + r) * B_PITCH + 4 * h : (4 * h) * B_PITCH + wn * TN * 32 + r);
+        const float* a = lds + buf * BUF + (AKC ? (wm * TM * 32 + r) * A_PITCH + 4 * h + kofs : (4 * h + kofs) * A_PITCH + wm * TM * 32 + r);
+        const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * TN * 32 + r) * B_PITCH + 4 * h + kofs : (4 * h + kofs) * B_PITCH + wn * TN * 32 + r);
 #pragma unroll
         for (int kb = kb_begin; kb < kb_end; kb += 8) {
             float fa[TM][4], fb[TN][4];
@@ -411,8 +420,8 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
         constexpr int HG = BK / 16;                  // k-groups of 8 per half tile
         float fa[2][HG][4], fb[2][HG][4];
         auto read_half = [&](int buf, int half, int slot) {
-            const float* a = lds + buf * BUF + (AKC ? (wm * 32 + r) * A_PITCH + 4 * h : (4 * h) * A_PITCH + wm * 32 + r);
-            const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * 32 + r) * B_PITCH + 4 * h : (4 * h) * B_PITCH + wn * 32 + r);
+            const float* a = lds + buf * BUF + (AKC ? (wm * 32 + r) * A_PITCH + 4 * h + kofs : (4 * h + kofs) * A_PITCH + wm * 32 + r);
+            const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * 32 + r) * B_PITCH + 4 * h + kofs : (4 * h + kofs) * B_PITCH + wn * 32 + r);
 #pragma unroll
             for (int q = 0; q < HG; ++q) {
                 const int kb = half * (BK / 2) + q * 8;
@@ -496,7 +505,29 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     }
 
     LG_TL(2);                                        // K loop done
-    if constexpr (kCanSplitK<BM, BN>) if (g.k_slices > 1) {
+    if constexpr (KG == 2) {
+        // K-group 1 hands its accumulators to group 0 through LDS (the staging buffers are free after the loop's last
+        // barrier): slot (wave-in-group, accumulator, register) holds one value per lane, so both sides move 256 B per
+        // wave instruction without bank conflicts.  Group 1 is done after that.
+        float* x = lds + (wl * TM * TN * 16) * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] += x[((i * TN + j) * 16 + e) * 64];
+    }
+    if constexpr (kCanSplitK<BM, BN, KG>) if (g.k_slices > 1) {
         // split-K, folded inside the launch (cdna_hip_programming.md, in-launch split-K recipe, write-through form).
         // Partial tiles go to the workspace in ACCUMULATOR layout - 16-byte piece ((i*TN + j)*4 + q) of thread tid at
         // byte (((i*TN + j)*4 + q)*NT + tid)*16 of the (batch, slice, tile) slab - so stores and the fold move 1 KiB per
@@ -607,15 +638,15 @@ __global__ void __launch_bounds__(WM * WN * 64) sgemm_mfma(GemmArgs g) {
     LG_TL(6);                                        // epilogue stores issued
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int KG>
 static void launch_layout(const GemmArgs& g, bool va, bool vb) {
-    dim3 grid(g.nwg), block(WM * WN * 64);
+    dim3 grid(g.nwg), block(WM * WN * KG * 64);
     hipStream_t s = rt().stream;
     constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 1;
-    if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD>), grid, block, 0, s, g);
-    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1>), grid, block, 0, s, g);
-    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1>), grid, block, 0, s, g);
-    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, 1>), grid, block, 0, s, g);
+    if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG>), grid, block, 0, s, g);
+    else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1, KG>), grid, block, 0, s, g);
+    else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1, KG>), grid, block, 0, s, g);
+    else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, 1, KG>), grid, block, 0, s, g);
 }
 
 #ifdef LG_GEMM_TIMELINE
@@ -626,7 +657,7 @@ static void lg_debug_timeline_state(unsigned long long* buf, int nwg, int slices
 }
 #endif
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int KG = 1>
 static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
     GemmArgs g = base;
     g.tiles_m = int((g.M + BM - 1) / BM);
@@ -638,7 +669,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     // with 0.65 us per K-tile of a lone 64x64 workgroup (0.45 for the two-wave tiles, 2.4 for 128x128) and
     // 2 + 0.6*slices us for writing, publishing and folding the slabs.
     int64_t slices = 1;
-    if (kCanSplitK<BM, BN> && tiles < 256 && g.K >= 4 * BK) {
+    if (kCanSplitK<BM, BN, KG> && tiles < 256 && g.K >= 4 * BK) {
         const double cus = rt().compute_units > 0 ? rt().compute_units : 256;
         const double t_iter = BM * BN >= 128 * 128 ? 2.4 : (BM * BN >= 64 * 64 ? 0.65 : 0.45);
         const int64_t k_tiles = (g.K + BK - 1) / BK;
@@ -662,7 +693,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         }
     }
     static const char* slices_env = getenv("LG_GEMM_SLICES");      // experiments only
-    if (kCanSplitK<BM, BN> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);
+    if (kCanSplitK<BM, BN, KG> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);
     g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;
     slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
     g.k_slices = int(slices);
@@ -697,10 +728,10 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     }
     // (measured and not kept: two wave groups per single-accumulator tile, each on half of every K-tile - the loop is bound
     // by the workgroup barrier, which more waves of the SAME workgroup do not hide: 25.9 -> 25.4 us at 1024x512x1024)
-    if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true>(g, va, vb);
-    else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false>(g, va, vb);
-    else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true>(g, va, vb);
-    else            launch_layout<BM, BN, BK, WM, WN, false, false>(g, va, vb);
+    if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true, KG>(g, va, vb);
+    else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false, KG>(g, va, vb);
+    else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true, KG>(g, va, vb);
+    else            launch_layout<BM, BN, BK, WM, WN, false, false, KG>(g, va, vb);
     if (slices > 1) return lg_free(g.W);     // stream-ordered: reused only by later launches
     return LG_OK;
 }
@@ -804,10 +835,36 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
             };
             const double c256 = fused_extras ? 1e300 : cost(256, 256, 0.88), c128 = cost(128, 128, 0.74), c64 = cost(64, 64, 0.85);
             tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
+            if (tile == 9 && batch == 1) {
+                // Too few 64x64 tiles to fill the chip: split K across workgroups (slabs + ticket + fold) or INSIDE a workgroup
+                // on a half-size tile (64x32 / 32x64 with two K-groups, one LDS exchange)?  Same model as launch_config (us):
+                // K-steps x time per step (+ hand-off), constants from tools/gemm_timeline.py - a K-group step stages 64 k and
+                // takes 0.81 us alone on a CU.  Measured at 1024x512x784: 15.9 -> 14.3 us; at 512x785x1024 a wash (kept split).
+                const int64_t t64 = nblocks(64, 64);
+                const int64_t k32 = (K + 31) / 32, k64 = (K + 63) / 64;
+                double best64 = 1e30;
+                for (int64_t sl = 1; sl <= 64 && (sl == 1 || sl * 2 <= k32); ++sl) {
+                    const double per_cu = double(t64 * sl) / double(cus);
+                    const double c = per_cu > 1.0 ? double(int64_t(per_cu + 0.999)) : 1.0;
+                    const double v = double((k32 + sl - 1) / sl) * (c <= 1.0 ? 0.68 : 0.43 * c + 0.17) + (sl > 1 ? 1.8 + 0.85 * double(sl) : 0.0);
+                    if (v < best64) best64 = v;
+                    if (t64 >= 256 || K < 128) break;            // launch_config splits only below 256 tiles
+                }
+                const int64_t t7 = nblocks(64, 32), t8 = nblocks(32, 64);
+                const int64_t tk = t7 <= t8 ? t7 : t8;
+                const double ck = double((tk + cus - 1) / cus);
+                const double kgroups = double(k64) * (ck <= 1.0 ? 0.81 : 0.5 * ck + 0.3) * (ck > 1.0 ? 1.0 : 1.0) + 0.3;
+                if (tk <= cus && kgroups + 0.5 < best64) tile = t7 <= t8 ? 7 : 8;
+            }
         }
         switch (tile) {
             case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
-            case 2:  if (!fused_extras) { rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch); break; }   // else: 128
+            case 2:
+                if (!fused_extras) rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch);
+                else               rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);      // extras are not compiled into the big tile
+                break;
+            case 7:  rc = launch_config<64, 32, 32, 2, 1, 2>(g, akc, bkc, va, vb, batch); break;   // K split inside the workgroup
+            case 8:  rc = launch_config<32, 64, 32, 1, 2, 2>(g, akc, bkc, va, vb, batch); break;
             case 9:  rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
             default: rc = launch_config<128, 128, 32, 2, 2>(g, akc, bkc, va, vb, batch); break;
         }

@@ -14,7 +14,7 @@
 //   head_bwd   dx = g @ W,  g_pre = dx * (pre >= 0),  dW = g^T @ act(x),  db = column sums of g
 //              one launch, three kinds of workgroups, no hand-off between them: "slab" workgroups own 8 columns of dW
 //              over ALL rows (g staged in LDS, sums over thread rows through LDS in a fixed order), "tile" workgroups
-//              write 64 x 32 tiles of dx / g_pre (every element needs only its row of g and its column of W), and one
+//              write 256 x 32 tiles of dx / g_pre (every element needs only its row of g and its column of W), and one
 //              workgroup finishes the loss of the forward pass
 //              - what linear.backward + relu.backward of the tape compute (cpu/ops.py:114-116, :229, func.py:50-56).
 //
@@ -36,11 +36,13 @@ __device__ __forceinline__ float relu_keep_nan(float x) { return (x != x) ? x : 
 __device__ __forceinline__ void finalize_loss(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss,
                                               float* lds4) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float v = 0.f;
-    for (int64_t i = tid; i < rows; i += 256) v += row_loss[i];
+    if (tid < 256) {                                   // 256 summing threads whatever the size of the workgroup: one order
+        float v = 0.f;
+        for (int64_t i = tid; i < rows; i += 256) v += row_loss[i];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) lds4[wave] = v;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) lds4[wave] = v;
+    }
     __syncthreads();
     if (tid == 0) loss[0] = (((lds4[0] + lds4[1]) + (lds4[2] + lds4[3])) * inv_n) * 0.5f;
 }
@@ -127,28 +129,33 @@ struct HeadBwd {
     int          g_dense;      // outs == OMAX and g 16-byte aligned: g is staged with float4 copies
 };
 
-constexpr int kHeadRows = 64, kHeadCols = 32;     // dx / gpre tile
-constexpr int kSlabCols = 8;                      // columns of dW one reducing workgroup owns (over ALL rows)
+constexpr int kHeadThreads = 1024;                 // 16 wavefronts: a slab workgroup has a CU to itself
+constexpr int kHeadRows = 256, kHeadCols = 32;     // dx / gpre tile
+constexpr int kSlabCols = 8;                       // columns of dW one reducing workgroup owns (over ALL rows)
 
 // Kinds of workgroups in one launch, none of which waits for another:
-//   slab workgroups  own 8 columns of dW for every row: 32 thread rows x 8 columns, g staged in LDS in chunks of up to
+//   slab workgroups  own 8 columns of dW for every row: 128 thread rows x 8 columns, g staged in LDS in chunks of up to
 //                    1024 rows, the activations of a chunk requested from memory before the chunk's g is staged (both
-//                    latencies overlap), sums over the thread rows through LDS in a fixed order.  No cross-workgroup
-//                    reduction, so no tickets and no partial slabs.  (Measured on the way here, 1024 x 512 x 10: a version
-//                    that reduced 64-row tiles across workgroups inside the launch took 14.3 us; this layout with g
-//                    staged element by element 13.3 us, of which 6.2 us were the staging loop - hence the float4 copy -
-//                    and 2.4 us the multiply-adds - hence FMA.)
-//   tile workgroups  write 64 x 32 tiles of dx (and gpre): each element needs its row of g and its column of W only.
+//                    latencies overlap), sums over the thread rows by shuffles inside a wavefront and through LDS across the
+//                    16 wavefronts, always in the same order.  No cross-workgroup reduction: no tickets, no partial slabs.
+//                    (Measured on the way here, 1024 x 512 x 10, back-to-back launches, an empty launch = 3.0 us: a version
+//                    that reduced 64-row tiles across workgroups inside the launch 14.3 us; slabs with 256 threads and g
+//                    staged element by element 13.3 us - 6.2 us of it that staging loop, 2.4 us the multiply-adds; float4
+//                    staging + FMA 8.5 us; 1024 threads per workgroup - a slab is latency-bound and has its CU to itself -
+//                    this version.)
+//   tile workgroups  write 256 x 32 tiles of dx (and gpre): each element needs its row of g and its column of W only.
 //   loss workgroup   the last one: finishes the scalar loss of head_fwd from its row sums.
 template <int OMAX>
-__global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
+__global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
     constexpr int CHUNK = OMAX <= 10 ? 1024 : 512;             // rows of g in LDS at a time (40 KiB / 32 KiB)
-    constexpr int RPT = CHUNK / 32;                            // rows per thread and chunk
+    constexpr int TR = kHeadThreads / kSlabCols;               // thread rows of a slab workgroup
+    constexpr int RPT = CHUNK / TR;                            // rows per thread and chunk
+    constexpr int NW = kHeadThreads / 64;
     __shared__ __attribute__((aligned(16))) float g_lds[CHUNK * OMAX];
-    __shared__ float red[32 * OMAX * (kSlabCols + 1)];
+    __shared__ float red[NW * OMAX * (kSlabCols + 1)];
     const int tid = threadIdx.x;
     if (int(blockIdx.x) < a.n_slabs) {
-        const int tc = tid & 7, tr = tid >> 3;
+        const int tc = tid & 7, tr = tid >> 3, wave = tid >> 6;
         const int slab = blockIdx.x;
         const int k = slab * kSlabCols + tc;
         const bool kin = k < a.hidden;
@@ -160,21 +167,21 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
             float xv[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int64_t r = c0 + tr + 32 * i;
+                const int64_t r = c0 + tr + TR * i;
                 xv[i] = (r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
             }
             __syncthreads();                                   // the previous chunk's g has been consumed
             const int64_t live = (a.rows - c0 < CHUNK ? a.rows - c0 : CHUNK) * OMAX;      // floats of g in this chunk
             if (a.g_dense) {
                 const float* src = a.g + c0 * OMAX;            // 16-byte aligned: c0 is a multiple of CHUNK
-                for (int i = tid * 4; i < CHUNK * OMAX; i += 1024) {
+                for (int i = tid * 4; i < CHUNK * OMAX; i += kHeadThreads * 4) {
                     float4 v = {0.f, 0.f, 0.f, 0.f};
                     if (i + 3 < live) v = *reinterpret_cast<const float4*>(src + i);
                     else if (i < live) { v.x = src[i]; if (i + 1 < live) v.y = src[i + 1]; if (i + 2 < live) v.z = src[i + 2]; }
                     *reinterpret_cast<float4*>(g_lds + i) = v;
                 }
             } else {
-                for (int i = tid; i < CHUNK * OMAX; i += 256) {
+                for (int i = tid; i < CHUNK * OMAX; i += kHeadThreads) {
                     const int rr = i / OMAX, j = i % OMAX;
                     g_lds[i] = (j < a.outs && c0 + rr < a.rows) ? a.g[(c0 + rr) * a.outs + j] : 0.f;
                 }
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
-                const int rr = tr + 32 * i;
+                const int rr = tr + TR * i;
                 const float h = a.relu ? relu_keep_nan(xv[i]) : xv[i];
 #pragma unroll
                 for (int j = 0; j < OMAX; ++j) acc[j] = __builtin_fmaf(g_lds[rr * OMAX + j], h, acc[j]);
@@ -191,20 +198,32 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
 #pragma unroll
                 for (int i = 0; i < RPT; ++i)
 #pragma unroll
-                    for (int j = 0; j < OMAX; ++j) dbacc[j] += g_lds[(tr + 32 * i) * OMAX + j];
+                    for (int j = 0; j < OMAX; ++j) dbacc[j] += g_lds[(tr + TR * i) * OMAX + j];
             }
         }
+        // the 8 thread rows of a wavefront (lanes c, c+8, ..., c+56 share column c), then the 16 wavefronts through LDS
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) {
-            red[(tr * OMAX + j) * (kSlabCols + 1) + tc] = acc[j];
-            if (does_db) red[(tr * OMAX + j) * (kSlabCols + 1) + kSlabCols] = dbacc[j];
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                acc[j] += __shfl_xor(acc[j], off, 64);
+                dbacc[j] += __shfl_xor(dbacc[j], off, 64);     // only column 0 of slab 0 carries values; the others sum zeros
+            }
+        }
+        if ((tid & 63) < kSlabCols) {
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) {
+                red[(wave * OMAX + j) * (kSlabCols + 1) + tc] = acc[j];
+                if (tc == 0) red[(wave * OMAX + j) * (kSlabCols + 1) + kSlabCols] = dbacc[j];
+            }
         }
         __syncthreads();
         if (tid < OMAX * (kSlabCols + 1)) {
             const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
             if (j < a.outs && (c < kSlabCols || slab == 0)) {
                 float s = 0.f;
-                for (int t = 0; t < 32; ++t) s += red[(t * OMAX + j) * (kSlabCols + 1) + c];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += red[(w * OMAX + j) * (kSlabCols + 1) + c];
                 if (c < kSlabCols) {
                     const int kk = slab * kSlabCols + c;
                     if (a.dw && kk < a.hidden) {
@@ -223,25 +242,27 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
         return;
     }
     // ---- dx / gpre tile ----
-    float* w_lds = red;                                         // [OMAX][kHeadCols]
+    constexpr int TRT = kHeadThreads / kHeadCols;              // 32 thread rows, 8 rows each
+    float* w_lds = red;                                         // [OMAX][kHeadCols] (fits: 16 * 10 * 9 >= 10 * 32)
+    static_assert(NW * (kSlabCols + 1) >= kHeadCols && kHeadRows * 16 <= CHUNK * OMAX, "LDS reuse");
     const int t = int(blockIdx.x) - a.n_slabs;
     const int cb = t % a.col_blocks;
     const int64_t r0 = int64_t(t / a.col_blocks) * kHeadRows;
     const int tc = tid & 31, tr = tid >> 5;
     const int k = cb * kHeadCols + tc;
     const bool kin = k < a.hidden;
-    float xv[kHeadRows / 8];
+    float xv[kHeadRows / TRT];
 #pragma unroll
-    for (int i = 0; i < kHeadRows / 8; ++i) {
-        const int64_t r = r0 + tr + 8 * i;
+    for (int i = 0; i < kHeadRows / TRT; ++i) {
+        const int64_t r = r0 + tr + TRT * i;
         xv[i] = (a.gpre && r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
     }
-    for (int i = tid; i < OMAX * kHeadCols; i += 256) {
+    for (int i = tid; i < OMAX * kHeadCols; i += kHeadThreads) {
         const int j = i / kHeadCols, c = i % kHeadCols;
         const int kk = cb * kHeadCols + c;
         w_lds[i] = (j < a.outs && kk < a.hidden) ? a.w[int64_t(j) * a.hidden + kk] : 0.f;
     }
-    for (int i = tid; i < kHeadRows * OMAX; i += 256) {
+    for (int i = tid; i < kHeadRows * OMAX; i += kHeadThreads) {
         const int rr = i / OMAX, j = i % OMAX;
         g_lds[i] = (j < a.outs && r0 + rr < a.rows) ? a.g[(r0 + rr) * a.outs + j] : 0.f;
     }
@@ -250,8 +271,8 @@ __global__ void __launch_bounds__(256) head_bwd(HeadBwd a) {
 #pragma unroll
     for (int j = 0; j < OMAX; ++j) w[j] = w_lds[j * kHeadCols + tc];
 #pragma unroll
-    for (int i = 0; i < kHeadRows / 8; ++i) {
-        const int rr = tr + 8 * i;
+    for (int i = 0; i < kHeadRows / TRT; ++i) {
+        const int rr = tr + TRT * i;
         const int64_t r = r0 + rr;
         if (r < a.rows && kin) {
             float s = 0.f;
@@ -328,10 +349,10 @@ extern "C" int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const floa
     const int omax = outs <= 4 ? 4 : (outs <= 8 ? 8 : (outs <= 10 ? 10 : 16));
     a.g_dense = (omax == outs && aligned16(g)) ? 1 : 0;
     hipStream_t s = rt().stream;
-    if (omax == 4)        hipLaunchKernelGGL(head_bwd<4>, dim3(unsigned(grid)), dim3(256), 0, s, a);
-    else if (omax == 8)   hipLaunchKernelGGL(head_bwd<8>, dim3(unsigned(grid)), dim3(256), 0, s, a);
-    else if (omax == 10)  hipLaunchKernelGGL(head_bwd<10>, dim3(unsigned(grid)), dim3(256), 0, s, a);
-    else                  hipLaunchKernelGGL(head_bwd<16>, dim3(unsigned(grid)), dim3(256), 0, s, a);
+    if (omax == 4)        hipLaunchKernelGGL(head_bwd<4>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);
+    else if (omax == 8)   hipLaunchKernelGGL(head_bwd<8>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);
+    else if (omax == 10)  hipLaunchKernelGGL(head_bwd<10>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);
+    else                  hipLaunchKernelGGL(head_bwd<16>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -211,159 +211,179 @@ def gpu_rank(args, rank, world):
         def forward(self, x):
             return self.l2(self.l1(x.reshape(-1, 784)).relu())
 
-    np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
-    model = MLP()
-    w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
-    model.map_parameters(lambda p: p.hip())
-    use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
-    overlap = multi and not (use_graph and args.comm_dispatch == "eager")
-    dp = DataParallel(model.parameters(), comm, flatten=use_graph, overlap=overlap)
-    dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
-    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
-                                device_step=use_graph)
-    if use_graph:
-        dp.attach(opt)                               # flat buckets: zero_grad = one flag, update = one launch
-    rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
-    x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
-    x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
-    labels = rng.randint(0, 10, 1024)
-    onehot_np = np.zeros((1024, 10), np.float32)
-    onehot_np[np.arange(1024), labels] = 1
-    onehot = HipTensor.from_numpy(onehot_np)
+    def mlp_leg(comm_dispatch):
+        """build model / optimizer / graphs and time the training step; raises if a capture fails or the replicas diverge"""
+        np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
+        model = MLP()
+        w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
+        model.map_parameters(lambda p: p.hip())
+        use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
+        overlap = multi and not (use_graph and comm_dispatch == "eager")
+        dp = DataParallel(model.parameters(), comm, flatten=use_graph, overlap=overlap)
+        dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
+        opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
+                                    device_step=use_graph)
+        if use_graph:
+            dp.attach(opt)                               # flat buckets: zero_grad = one flag, update = one launch
+        rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
+        x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
+        x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
+        labels = rng.randint(0, 10, 1024)
+        onehot_np = np.zeros((1024, 10), np.float32)
+        onehot_np[np.arange(1024), labels] = 1
+        onehot = HipTensor.from_numpy(onehot_np)
 
-    def forward_backward():
-        loss = light.loss.mse(model(x), onehot)
-        opt.zero_grad()
-        loss.backward()
-        return loss
-
-    def eager_step():
-        loss = forward_backward()
-        dp.sync_gradients()
-        opt.step()
-        return loss
-
-    step = eager_step
-    comm_in_graph = False
-    unroll = 1
-    # three eager steps first: they allocate optimizer state, fill the pool, load kernels and teach DataParallel(overlap=True)
-    # where the last gradient write is - and their losses are the parity check against the CPU backend on the same problem
-    first_losses = [eager_step().item() for _ in range(3)]
-    if use_graph:
-        n_params = len(opt.parameters)
-        g_all = None
-        if not multi or args.comm_dispatch == "graph":
-            # ONE graph for the whole step.  With a communicator the all-reduce is a forked branch of it: started on the
-            # communication stream after the last parameter-gradient kernel, joined before the optimizer kernel.
-            try:
-                g_all = HipGraph()
-                with g_all.capture():
-                    graph_loss = eager_step()
-                comm_in_graph = multi
-            except L.HipError as e:
-                if not multi:
-                    raise
-                sys.stderr.write("[bench] rank %d: capturing the collective failed (%s); using eager collectives\n" % (rank, e))
-                g_all = None
-                dp.set_overlap(False)
-            opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
-        if g_all is not None:
-            def step():
-                g_all.replay()
-                opt.on_graph_replay()
-                return graph_loss
-            # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
-            # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
-            # on the resident batch; the timed loop below still performs exactly --steps of them.
-            unroll = max(1, min(args.graph_steps, args.steps))
-            while args.steps % unroll:
-                unroll -= 1
-            if unroll > 1:
-                g_multi = HipGraph()
-                with g_multi.capture():
-                    for _ in range(unroll):
-                        multi_loss = eager_step()
-                opt.t -= unroll * n_params
-        else:
-            # fallback (--comm-dispatch eager): forward+backward replay from a graph; the RCCL all-reduce and the optimizer
-            # launch follow as host calls on the same stream
-            g_fb = HipGraph()
-            with g_fb.capture():
-                graph_loss = forward_backward()
-
-            def step():
-                g_fb.replay()
-                dp.sync_gradients()
-                opt.step()
-                return graph_loss
-
-    for _ in range(args.warmup):
-        loss = step()
-    if unroll > 1:
-        g_multi.replay()                             # untimed: first launch of the multi-step graph
-        opt.on_graph_replay(unroll)
-    fence()
-    t0 = time.perf_counter()
-    if unroll > 1:
-        for _ in range(args.steps // unroll):
-            g_multi.replay()
-            opt.on_graph_replay(unroll)
-        loss = multi_loss
-    else:
-        for _ in range(args.steps):
-            loss = step()
-    fence()
-    mine = time.perf_counter() - t0
-    elapsed = wall_max(mine)
-    per_rank = gather(args.steps / mine)
-    final_loss = loss.item()
-    assert np.isfinite(final_loss), final_loss
-    steps_per_s = world * args.steps / elapsed
-    digest = dp.parameter_digest()
-    if multi:                                        # replicas must still be identical
-        d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
-        comm.allreduce_max_(d)
-        dmax, dmin = d.numpy()
-        assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
-
-    # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
-    eager_steps = max(10, min(args.steps, 100))
-    for _ in range(5):
-        eager_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(eager_steps):
-        eager_step()
-    fence()
-    eager_steps_per_s = world * eager_steps / wall_max(time.perf_counter() - t0)
-
-    # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
-    # computes and drops, is then not computed at all.  Reported next to `value`, never as `value`.
-    data_input_steps_per_s = None
-    if use_graph and not multi:
-        x_data = HipTensor.from_numpy(x_np, requires_grad=False)
-
-        def data_step():
-            loss = light.loss.mse(model(x_data), onehot)
+        def forward_backward():
+            loss = light.loss.mse(model(x), onehot)
             opt.zero_grad()
             loss.backward()
+            return loss
+
+        def eager_step():
+            loss = forward_backward()
+            dp.sync_gradients()
             opt.step()
             return loss
-        for _ in range(2):
-            data_step()
-        g_data = HipGraph()
-        with g_data.capture():
-            data_step()
-        opt.t -= n_params
+
+        step = eager_step
+        comm_in_graph = False
+        unroll = 1
+        # three eager steps first: they allocate optimizer state, fill the pool, load kernels and teach DataParallel(overlap=True)
+        # where the last gradient write is - and their losses are the parity check against the CPU backend on the same problem
+        first_losses = [eager_step().item() for _ in range(3)]
+        if use_graph:
+            n_params = len(opt.parameters)
+            g_all = None
+            if not multi or comm_dispatch == "graph":
+                # ONE graph for the whole step.  With a communicator the all-reduce is a forked branch of it: started on the
+                # communication stream after the last parameter-gradient kernel, joined before the optimizer kernel.
+                try:
+                    g_all = HipGraph()
+                    with g_all.capture():
+                        graph_loss = eager_step()
+                    comm_in_graph = multi
+                except L.HipError:
+                    raise                        # multi: gpu_rank repeats the leg with host-launched collectives
+                opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
+            if g_all is not None:
+                def step():
+                    g_all.replay()
+                    opt.on_graph_replay()
+                    return graph_loss
+                # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
+                # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
+                # on the resident batch; the timed loop below still performs exactly --steps of them.
+                unroll = max(1, min(args.graph_steps, args.steps))
+                while args.steps % unroll:
+                    unroll -= 1
+                if unroll > 1:
+                    g_multi = HipGraph()
+                    with g_multi.capture():
+                        for _ in range(unroll):
+                            multi_loss = eager_step()
+                    opt.t -= unroll * n_params
+            else:
+                # fallback (--comm-dispatch eager): forward+backward replay from a graph; the RCCL all-reduce and the optimizer
+                # launch follow as host calls on the same stream
+                g_fb = HipGraph()
+                with g_fb.capture():
+                    graph_loss = forward_backward()
+
+                def step():
+                    g_fb.replay()
+                    dp.sync_gradients()
+                    opt.step()
+                    return graph_loss
+
         for _ in range(args.warmup):
-            g_data.replay()
+            loss = step()
+        if unroll > 1:
+            g_multi.replay()                             # untimed: first launch of the multi-step graph
+            opt.on_graph_replay(unroll)
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            g_data.replay()
+        if unroll > 1:
+            for _ in range(args.steps // unroll):
+                g_multi.replay()
+                opt.on_graph_replay(unroll)
+            loss = multi_loss
+        else:
+            for _ in range(args.steps):
+                loss = step()
         fence()
-        data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
-        opt.on_graph_replay(args.warmup + args.steps)
+        mine = time.perf_counter() - t0
+        elapsed = wall_max(mine)
+        per_rank = gather(args.steps / mine)
+        final_loss = loss.item()
+        assert np.isfinite(final_loss), final_loss
+        steps_per_s = world * args.steps / elapsed
+        digest = dp.parameter_digest()
+        if multi:                                        # replicas must still be identical
+            d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
+            comm.allreduce_max_(d)
+            dmax, dmin = d.numpy()
+            assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
+
+        # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
+        eager_steps = max(10, min(args.steps, 100))
+        for _ in range(5):
+            eager_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(eager_steps):
+            eager_step()
+        fence()
+        eager_steps_per_s = world * eager_steps / wall_max(time.perf_counter() - t0)
+
+        # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
+        # computes and drops, is then not computed at all.  Reported next to `value`, never as `value`.
+        data_input_steps_per_s = None
+        if use_graph and not multi:
+            x_data = HipTensor.from_numpy(x_np, requires_grad=False)
+
+            def data_step():
+                loss = light.loss.mse(model(x_data), onehot)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                return loss
+            for _ in range(2):
+                data_step()
+            g_data = HipGraph()
+            with g_data.capture():
+                data_step()
+            opt.t -= n_params
+            for _ in range(args.warmup):
+                g_data.replay()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g_data.replay()
+            fence()
+            data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
+            opt.on_graph_replay(args.warmup + args.steps)
+        return dict(steps_per_s=steps_per_s, elapsed=elapsed, per_rank=per_rank, final_loss=final_loss, first_losses=first_losses,
+                    eager_steps_per_s=eager_steps_per_s, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
+                    unroll=unroll, use_graph=use_graph, overlap=dp.overlap, w0=w0, x_np=x_np, onehot_np=onehot_np)
+
+    # The exchange inside the captured graph is the design (DESIGN.md 5); should capturing the collective fail, or the replicas
+    # come out different after the timed steps, the whole leg is repeated with host-launched collectives and that is reported.
+    modes = ["graph", "eager"] if (multi and args.comm_dispatch == "graph") else [args.comm_dispatch]
+    R, fallback_reason = None, None
+    for k, mode in enumerate(modes):
+        try:
+            R = mlp_leg(mode)
+            break
+        except (L.HipError, AssertionError) as e:
+            if k == len(modes) - 1:
+                raise
+            fallback_reason = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("[bench] rank %d: the leg with the in-graph exchange failed (%s); repeating with host-launched collectives\n"
+                             % (rank, fallback_reason))
+    steps_per_s, elapsed, per_rank, final_loss, first_losses = (R[k] for k in ("steps_per_s", "elapsed", "per_rank", "final_loss", "first_losses"))
+    eager_steps_per_s, data_input_steps_per_s, comm_in_graph, unroll, use_graph = (
+        R[k] for k in ("eager_steps_per_s", "data_input_steps_per_s", "comm_in_graph", "unroll", "use_graph"))
+    w0, x_np, onehot_np = R["w0"], R["x_np"], R["onehot_np"]
 
     ranks_info = {"world_size": world, "communicator": type(comm).__name__,
                   "communicator_ranks": comm.ranks_seen() if multi else 1,          # lg_comm_rank: what RCCL itself reports
@@ -372,8 +392,9 @@ def gpu_rank(args, rank, world):
                               ("torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"),
                   "exchange": None if not multi else
                               ("all-reduce forked inside the captured step, overlapped with the input-gradient GEMM" if comm_in_graph else
-                               ("host-launched all-reduce on the communication stream, overlapped" if dp.overlap else
-                                "host-launched all-reduce on the compute stream after backward"))}
+                               ("host-launched all-reduce on the communication stream, overlapped" if R["overlap"] else
+                                "host-launched all-reduce on the compute stream after backward")),
+                  "in_graph_exchange_fallback": fallback_reason}
 
     out = {
         "metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",

@@ -211,6 +211,91 @@ __global__ void __launch_bounds__(256) red_cols(const float* __restrict__ in, fl
     if (live) out[o] = d.accumulate ? out[o] + v : v;
 }
 
+// ---- columns of a row-major matrix: 64-column x many-row tiles -------------------------------------
+// The common leading-axis reduction (kept axis contiguous, one reduced axis: `sum((N, C) -> (C,))`, the bias un-broadcast
+// of func.py:50-56).  red_cols gives every thread ONE column and at most four loads in flight: at 64 MiB that was 2.8 TB/s
+// (35 % of the 8 TB/s spec), bound by memory latency and by a fold over 32 partials.  Here a workgroup owns 64 columns as
+// 16 float4 lanes x 16 thread rows, each thread keeps four 16-byte loads in flight, the thread rows combine through LDS, and
+// only a few row chunks (<= 16) are left to fold across workgroups - all their partials are fetched at once.
+template <int OP>
+__global__ void __launch_bounds__(256) red_cols_tile(const float* __restrict__ in, float* out, float* partial, int* tickets,
+                                                     int64_t n_out, int64_t rlen, int64_t rstride, int64_t chunk, int accumulate) {
+    __shared__ float lds[16][64 + 4];
+    __shared__ int arrived_last;
+    const int tid = threadIdx.x, tc = tid & 15, tr = tid >> 4;
+    const int64_t col = int64_t(blockIdx.x) * 64 + tc * 4;
+    const bool live = col < n_out;                                   // n_out is a multiple of 4
+    const int64_t begin = int64_t(blockIdx.y) * chunk;
+    int64_t end = begin + chunk;
+    if (end > rlen) end = rlen;
+    const float id = Red<OP>::identity();
+    constexpr int U = 8;                                             // 16-byte loads in flight per thread
+    float4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = make_float4(id, id, id, id);
+    if (live) {
+        const float* p = in + col;
+        int64_t r = begin + tr;
+        for (; r + 16 * (U - 1) < end; r += 16 * U) {
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const float4*>(p + (r + 16 * u) * rstride);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a[u].x = Red<OP>::comb(a[u].x, x[u].x); a[u].y = Red<OP>::comb(a[u].y, x[u].y);
+                a[u].z = Red<OP>::comb(a[u].z, x[u].z); a[u].w = Red<OP>::comb(a[u].w, x[u].w);
+            }
+        }
+        for (; r < end; r += 16) {
+            const float4 x = *reinterpret_cast<const float4*>(p + r * rstride);
+            a[0].x = Red<OP>::comb(a[0].x, x.x); a[0].y = Red<OP>::comb(a[0].y, x.y);
+            a[0].z = Red<OP>::comb(a[0].z, x.z); a[0].w = Red<OP>::comb(a[0].w, x.w);
+        }
+    }
+#pragma unroll
+    for (int w = U / 2; w >= 1; w /= 2)
+#pragma unroll
+        for (int u = 0; u < w; ++u) {
+            a[u].x = Red<OP>::comb(a[u].x, a[u + w].x); a[u].y = Red<OP>::comb(a[u].y, a[u + w].y);
+            a[u].z = Red<OP>::comb(a[u].z, a[u + w].z); a[u].w = Red<OP>::comb(a[u].w, a[u + w].w);
+        }
+    const float4 t = a[0];
+    lds[tr][tc * 4 + 0] = t.x; lds[tr][tc * 4 + 1] = t.y; lds[tr][tc * 4 + 2] = t.z; lds[tr][tc * 4 + 3] = t.w;
+    __syncthreads();
+    const int64_t o = int64_t(blockIdx.x) * 64 + tid;                // threads 0..63: one output column each
+    float v = id;
+    if (tid < 64) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v = Red<OP>::comb(v, lds[k][tid]);
+    }
+    const int splits = gridDim.y;
+    if (splits > 1) {
+        if (tid < 64 && o < n_out) __hip_atomic_store(partial + int64_t(blockIdx.y) * n_out + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int* ticket = tickets + blockIdx.x;
+            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = order == splits - 1;
+            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived_last = last;
+        }
+        __syncthreads();
+        if (!arrived_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < 64 && o < n_out) {
+            float x[16];                                             // splits <= 16: every partial of this column in flight at once
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                x[k] = k < splits ? __hip_atomic_load(partial + int64_t(k) * n_out + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : id;
+            v = id;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v = Red<OP>::comb(v, x[k]);
+        }
+    }
+    if (tid < 64 && o < n_out) out[o] = accumulate ? out[o] + v : v;
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 
 // collapse a list of (shape, stride) pairs in place; returns the new count (>= 1)
@@ -272,6 +357,32 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
         return lg_free(partial);   // stream-ordered: the block is only reused by later launches
     }
 
+    // columns of a row-major matrix (kept axis contiguous, one strided reduced axis): the tiled kernel
+    if (d.nk == 1 && d.nr == 1 && d.kstride[0] == 1 && d.n_out % 4 == 0 && d.rstride[0] % 4 == 0 && aligned16(in) && d.rlen >= 64 &&
+        d.n_out >= 64) {
+        const int64_t bx = (d.n_out + 63) / 64;
+        static const char* tw_env = getenv("LG_RED_TILE_WGS");      // experiments only
+        // workgroups in total: one per CU while the matrix fits the 256 MiB Infinity Cache, two beyond (measured, sum(axis=0):
+        // 4096^2: 256 -> 13.0 us, 512 -> 14.1, 1024 -> 16.7 (red_cols: 23.7); 16384 x 8192: 256 -> 108 us, 384-512 -> 86, 1024 -> 97
+        // (red_cols: 91)); few enough row chunks that the fold fetches every partial at once
+        const int64_t target = tw_env ? atoi(tw_env) : (d.n_out * d.rlen * 4 <= (int64_t(128) << 20) ? 256 : 512);
+        int64_t splits = (target + bx - 1) / bx;
+        if (splits > 16) splits = 16;
+        if (splits * 64 > d.rlen) splits = d.rlen / 64;            // at least 64 rows per workgroup
+        if (splits < 1) splits = 1;
+        int64_t chunk = ((d.rlen + splits - 1) / splits + 15) & ~int64_t(15);
+        splits = (d.rlen + chunk - 1) / chunk;
+        if (bx <= rt().n_gemm_tickets && bx < (int64_t(1) << 31)) {
+            float* partial = nullptr;
+            if (splits > 1) {
+                int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
+                if (rc != LG_OK) return rc;
+            }
+            hipLaunchKernelGGL((red_cols_tile<OP>), dim3(unsigned(bx), unsigned(splits)), dim3(256), 0, s, in, out, partial,
+                               rt().gemm_tickets, d.n_out, d.rlen, d.rstride[0], chunk, d.accumulate);
+            return splits > 1 ? lg_free(partial) : LG_OK;
+        }
+    }
     // general / column reduce
     int64_t blocks_x = (d.n_out + 255) / 256;
     int64_t splits = 1;

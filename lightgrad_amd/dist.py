@@ -122,16 +122,23 @@ def _exchange_unique_id(rank, make_id, path, timeout=300.0):
 class _c_stdout_to_stderr(object):
     """redirect file descriptor 1 to file descriptor 2 for the duration of a `with` block (C libraries included)"""
 
-    def __enter__(self):
+    @staticmethod
+    def _flush_all():
         import sys
         sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)      # the C library's own buffers: a banner printf()ed into a pipe sits there until exit
+        except (OSError, AttributeError):
+            pass
+
+    def __enter__(self):
+        self._flush_all()
         self._saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
-        import sys
-        sys.stdout.flush()
+        self._flush_all()                       # ... so push it out while descriptor 1 still points at stderr
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False

@@ -301,6 +301,18 @@ int lg_put_axis(int itemsize, void* dst, int64_t outer, int64_t axis_len, int64_
 int lg_scatter_add_axis_f32(float* dst, int64_t outer, int64_t axis_len, int64_t inner,
                             const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const float* src);
 
+/* ---- two independent products in one launch ----------------------------------------------------------
+ * lg_gemm_pair_begin(); <product 1>; <product 2>; lg_gemm_pair_end();   with products issued through
+ * lg_gemm_f32 / lg_gemm_rowsum_f32 / lg_gemm_fused_f32.  If the first resolves to the 64x64 tile with an
+ * M-contiguous A and N-contiguous B (dW = g^T @ x of nn.Linear's backward) and the second to the 64x64 tile
+ * with a K-contiguous A and N-contiguous B (dx = g @ W), neither is launched until _end, which launches both
+ * as ONE grid: their workgroups share the CUs and hide each other's waits, and one launch floor disappears
+ * (dot.backward of the reference is two kernels.dot calls: opencl/ops.py:127-132).  Any other product inside
+ * the bracket runs as usual, after whatever was pending - results never depend on the bracket.  The two
+ * products must not read each other's outputs. */
+int lg_gemm_pair_begin(void);
+int lg_gemm_pair_end(void);
+
 /* ---- the skinny output layer and its loss (csrc/head.hip) ------------------------
  * An nn.Linear with at most 16 output features (a classifier head; reference nn.py:90-96) followed by
  * loss.mse (loss.py:4-12), forward and backward, in two launches.  `relu` != 0: `x` is the PRE-activation of

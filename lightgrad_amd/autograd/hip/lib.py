@@ -69,6 +69,8 @@ PROTOTYPES = {
     "lg_reduce_acc": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p, c_int]),
     "lg_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
+    "lg_gemm_pair_begin": (c_int, []),
+    "lg_gemm_pair_end": (c_int, []),
     "lg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_double, c_int]),
     "lg_adam_step_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,

@@ -1044,6 +1044,21 @@ class linear(Function):
         # is reported for them - tensor.py:118's `grad += g` without the temporary and the extra pass
         dw = dx = db = None
         want_db = has_bias and bias.requires_grad
+        # dW (+ db) and dx are independent products: when both are wanted they go out as ONE launch (lg_gemm_pair_*) - unless a
+        # data-parallel exchange hangs on the weight gradient's kernel being enqueued the moment it is reported written
+        paired = (weight.requires_grad and x.requires_grad and g2._shape[0] > 0 and weight._grad_written_hook is None
+                  and (bias is None or bias._grad_written_hook is None))
+        if paired:
+            _l.check(_l.lib().lg_gemm_pair_begin())
+        try:
+            return linear._backward_products(x, x2, weight, bias, has_bias, want_db, g2)
+        finally:
+            if paired:
+                _l.check(_l.lib().lg_gemm_pair_end())
+
+    @staticmethod
+    def _backward_products(x, x2, weight, bias, has_bias, want_db, g2):
+        dw = dx = db = None
         if weight.requires_grad and want_db and g2._shape[0] > 0:
             # dW and db from one launch: db = column sums of g = row sums of g^T, a virtual extra column of the product
             acc_w, acc_b = weight._grad_accumulator(), bias._grad_accumulator()

@@ -119,8 +119,16 @@ template <int BM, int BN, int KG = 1> constexpr bool kCanSplitK = kHasExtras<BM,
 // group 0 through LDS.  For outputs with too few 64x64 tiles to fill the chip this replaces the cross-workgroup split-K (slab
 // write + drain + ticket + fold = 2.6 us of a 14.6 us launch, profiles/r2/gemm_timeline_v1.txt) by one LDS exchange: a 64x32
 // tile with 2 x 2 waves does per wave exactly the MFMA work of a 64x64 tile with 2 K-slices, one workgroup per CU.
+template <int BM, int BN, int BK, bool AKC, bool BKC, int KG>
+constexpr int gemm_lds_floats() {
+    constexpr int BKS = BK * KG;
+    return 2 * ((AKC ? BM * (BKS + 4) : BKS * BM) + (BKC ? BN * (BKS + 4) : BKS * BN));
+}
+
+// One output tile (or K-slice of one): the whole kernel body, as a device function of the workgroup index so that ONE launch
+// can work on two independent products (sgemm_pair below).
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
-__global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
+__device__ __forceinline__ void sgemm_tile(const GemmArgs& g, const int bid, float* __restrict__ lds) {
     constexpr int NT = WM * WN * KG * 64;
     constexpr int BKS = BK * KG;                         // k-values staged per K-step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -132,7 +140,7 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
     constexpr int A_ELEMS = BM * BKS / NT, B_ELEMS = BN * BKS / NT;   // floats staged per thread
     static_assert(A_ELEMS % 4 == 0 && B_ELEMS % 4 == 0, "staging must divide into float4");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+    static_assert(2 * (A_TILE + B_TILE) == gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>(), "LDS size");
     // buffer b: A tile at lds + b*(A_TILE+B_TILE), B tile right behind it
     constexpr int BUF = A_TILE + B_TILE;
 
@@ -145,7 +153,7 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
     LG_TL(0);                                        // workgroup entered
 
     // tile coordinates
-    const int id = xcd_remap(blockIdx.x, g.nwg);
+    const int id = xcd_remap(bid, g.nwg);
     const int per_batch = g.tiles_m * g.tiles_n;
     const int bs = g.div_per_batch.div(id);        // (batch, k-slice) pair
     const int batch = g.div_slices.div(bs), slice = bs - batch * g.k_slices;
@@ -638,6 +646,26 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
     LG_TL(6);                                        // epilogue stores issued
 }
 
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
+__global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>()];
+    sgemm_tile<BM, BN, BK, WM, WN, AKC, BKC, VA, VB, PD, KG>(g, blockIdx.x, lds);
+}
+
+// Two independent products in ONE launch: workgroups [0, first.nwg) work on the first, the rest on the second.  Made for the
+// pair every Linear's backward produces - dW (+ db) = g^T @ x and dx = g @ W: both have too few 64x64 tiles to give a CU more
+// than one workgroup, and a lone workgroup leaves the matrix cores idle during its waits (0.68 us per K-tile against 0.43 us
+// of MFMAs); together their workgroups share the CUs and interleave (0.51 us per K-tile each when two are resident), and one
+// launch floor (3 us) disappears.  Layouts: the first product A^T-form (M-contiguous A, N-contiguous B), the second
+// K-contiguous A and N-contiguous B - what dense row-major g, x, W give.
+template <int PD>
+__global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, GemmArgs second) {
+    constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, false, 1>();
+    __shared__ __attribute__((aligned(16))) float lds[L1 > L2 ? L1 : L2];
+    if (int(blockIdx.x) < first.nwg) sgemm_tile<64, 64, 32, 2, 2, false, false, true, true, PD, 1>(first, blockIdx.x, lds);
+    else                             sgemm_tile<64, 64, 32, 2, 2, true, false, true, true, PD, 1>(second, int(blockIdx.x) - first.nwg, lds);
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int KG>
 static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     dim3 grid(g.nwg), block(WM * WN * KG * 64);
@@ -647,6 +675,54 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1, KG>), grid, block, 0, s, g);
     else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1, KG>), grid, block, 0, s, g);
     else           hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, false, 1, KG>), grid, block, 0, s, g);
+}
+
+// ---- two products in one launch (lg_gemm_pair_begin / _end) --------------------------------------------------------------
+// Between begin and end, up to two products that resolve to the 64x64 tile in the layouts of sgemm_pair_wgrad_xgrad are
+// prepared but not launched; end launches them together.  Anything else flushes what is pending (single launches, in call
+// order) and runs as usual - so the bracket never changes results, only how many launches there are.
+struct PairState {
+    int      active = 0;       // 0: no bracket; 1: collecting; 2: bracket open but no longer collecting
+    int      count = 0;
+    GemmArgs args[2];
+};
+static PairState& pair_state() { static PairState p; return p; }
+
+static void pair_launch_single(const GemmArgs& g, int slot) {
+    dim3 grid(g.nwg), block(256);
+    constexpr int PD = kSmallTilePrefetch;
+    if (slot == 0) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, false, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
+    else           hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
+}
+
+static int pair_flush(bool keep_collecting) {
+    PairState& P = pair_state();
+    int rc = LG_OK;
+    if (P.count == 2) {
+        hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
+                           P.args[0], P.args[1]);
+    } else if (P.count == 1) {
+        pair_launch_single(P.args[0], 0);
+    }
+    for (int i = 0; i < P.count; ++i)
+        if (P.args[i].W) { const int r = lg_free(P.args[i].W); if (r != LG_OK) rc = r; }       // stream-ordered: reused by later launches only
+    P.count = 0;
+    if (!keep_collecting && P.active) P.active = 2;
+    return rc;
+}
+
+// true: `g` (fully prepared, workspace allocated) has been taken over and will be launched by lg_gemm_pair_end
+static bool pair_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, int64_t batch) {
+    PairState& P = pair_state();
+    if (P.active != 1) return false;
+    const int slot = P.count;
+    const bool fits = slot < 2 && va && vb && batch == 1 && !bkc && (slot == 0 ? !akc : akc);
+    const int64_t first_tiles = slot == 1 ? int64_t(P.args[0].tiles_m) * P.args[0].tiles_n : 0;
+    if (!fits || first_tiles + int64_t(g.tiles_m) * g.tiles_n > rt().n_gemm_tickets) return false;
+    g.tickets = rt().gemm_tickets + first_tiles;           // the two products fold their K-slices with disjoint tickets
+    P.args[slot] = g;
+    P.count = slot + 1;
+    return true;
 }
 
 #ifdef LG_GEMM_TIMELINE
@@ -728,6 +804,13 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     }
     // (measured and not kept: two wave groups per single-accumulator tile, each on half of every K-tile - the loop is bound
     // by the workgroup barrier, which more waves of the SAME workgroup do not hide: 25.9 -> 25.4 us at 1024x512x1024)
+    if constexpr (BM == 64 && BN == 64 && WM == 2 && WN == 2 && KG == 1) {
+        if (pair_try_defer(g, akc, bkc, va, vb, batch)) return LG_OK;
+    }
+    if (pair_state().count) {                         // something else inside a pair bracket: what is pending goes first
+        const int prc = pair_flush(false);
+        if (prc != LG_OK) return prc;
+    }
     if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true, KG>(g, va, vb);
     else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false, KG>(g, va, vb);
     else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true, KG>(g, va, vb);
@@ -929,3 +1012,23 @@ extern "C" int lg_debug_gemm_timeline(unsigned long long* host, int max_wgs, int
     return LG_OK;
 }
 #endif
+
+extern "C" int lg_gemm_pair_begin(void) {
+    LG_REQUIRE_INIT();
+    PairState& P = lg::pair_state();
+    LG_ARG(P.active == 0, "lg_gemm_pair_begin: a pair bracket is already open");
+    P.active = 1;
+    P.count = 0;
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_pair_end(void) {
+    LG_REQUIRE_INIT();
+    PairState& P = lg::pair_state();
+    LG_ARG(P.active != 0, "lg_gemm_pair_end: no pair bracket is open");
+    const int rc = lg::pair_flush(true);
+    P.active = 0;
+    if (rc != LG_OK) return rc;
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}

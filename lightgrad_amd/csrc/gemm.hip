@@ -681,6 +681,9 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
 // Between begin and end, up to two products that resolve to the 64x64 tile in the layouts of sgemm_pair_wgrad_xgrad are
 // prepared but not launched; end launches them together.  Anything else flushes what is pending (single launches, in call
 // order) and runs as usual - so the bracket never changes results, only how many launches there are.
+#ifdef LG_GEMM_TIMELINE
+static void lg_debug_timeline_state(unsigned long long* buf, int nwg, int slices, int tiles);
+#endif
 struct PairState {
     int      active = 0;       // 0: no bracket; 1: collecting; 2: bracket open but no longer collecting
     int      count = 0;
@@ -699,6 +702,12 @@ static int pair_flush(bool keep_collecting) {
     PairState& P = pair_state();
     int rc = LG_OK;
     if (P.count == 2) {
+#ifdef LG_GEMM_TIMELINE
+        if (P.args[0].tl) {
+            (void)hipMemsetAsync(P.args[0].tl, 0, size_t(P.args[0].nwg + P.args[1].nwg) * 64, rt().stream);
+            lg_debug_timeline_state(P.args[0].tl, P.args[0].nwg + P.args[1].nwg, P.args[0].k_slices * 100 + P.args[1].k_slices, P.args[0].nwg);
+        }
+#endif
         hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
                            P.args[0], P.args[1]);
     } else if (P.count == 1) {
@@ -770,6 +779,11 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     }
     static const char* slices_env = getenv("LG_GEMM_SLICES");      // experiments only
     if (kCanSplitK<BM, BN, KG> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);
+    static const char* pair_slices_env = getenv("LG_GEMM_PAIR_SLICES");      // experiments only: "<first>,<second>"
+    if (kCanSplitK<BM, BN, KG> && pair_slices_env && pair_state().active == 1) {
+        int s0 = 0, s1 = 0;
+        if (sscanf(pair_slices_env, "%d,%d", &s0, &s1) == 2) { const int v = pair_state().count == 0 ? s0 : s1; if (v >= 1) slices = v; }
+    }
     g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;
     slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
     g.k_slices = int(slices);

@@ -36,6 +36,17 @@ cases = {
     "dW1   g1^T @ x   (512x784, K=1024) TN": gemm(1, 0, 512, 784, 1024, g1, 512, x, 784),
     "dW1+db1 rowsum   (512x785, K=1024) TN": lambda: L.check(lib.lg_gemm_rowsum_f32(1, 0, 512, 784, 1024, g1.ptr, 512, x.ptr, 784, out.ptr, 784, 0, db.ptr, 0)),
 }
+
+
+def pair():
+    L.check(lib.lg_gemm_pair_begin())
+    L.check(lib.lg_gemm_rowsum_f32(1, 0, 512, 784, 1024, g1.ptr, 512, x.ptr, 784, out.ptr, 784, 0, db.ptr, 0))
+    L.check(lib.lg_gemm_f32(0, 0, 1024, 784, 512, g1.ptr, 512, 0, w1.ptr, 784, 0, out2.ptr, 784, 0, 1, 0))
+    L.check(lib.lg_gemm_pair_end())
+
+
+out2 = HipTensor.empty((1024 * 1024,), requires_grad=False)
+cases["PAIR dW1+db1 | dx in one launch ('tiles' = workgroups of the first product)"] = pair
 names = ["entry -> first K-tile in LDS", "K loop", "slab write + drain", "ticket", "fold (last arriver)", "epilogue"]
 for name, fn in cases.items():
     runs = []
@@ -51,6 +62,12 @@ for name, fn in cases.items():
     rel = (tl - t0) / 100.0                                         # microseconds since the first workgroup entered
     rel[tl == 0] = np.nan
     print("%s   %d workgroups (%d tiles x %d K-slices)" % (name, n, tiles.value, sl.value))
+    if name.startswith("PAIR"):
+        n1 = tiles.value
+        for tag, part in (("first product ", rel[:n1]), ("second product", rel[n1:])):
+            print("   %s: entry median +%.2f us (last +%.2f), K loop median %.2f us (p90 %.2f), finished median +%.2f us, last +%.2f us"
+                  % (tag, np.nanmedian(part[:, 0]), np.nanmax(part[:, 0]), np.nanmedian(part[:, 2] - part[:, 1]),
+                     np.nanpercentile(part[:, 2] - part[:, 1], 90), np.nanmedian(np.nanmax(part, axis=1)), np.nanmax(part)))
     print("   workgroup entry: median +%.2f us, p90 +%.2f, last +%.2f" % (np.nanmedian(rel[:, 0]), np.nanpercentile(rel[:, 0], 90), np.nanmax(rel[:, 0])))
     for i, ph in enumerate(names):
         d = rel[:, i + 1] - rel[:, i]

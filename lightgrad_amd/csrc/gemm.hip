@@ -125,531 +125,15 @@ constexpr int gemm_lds_floats() {
     return 2 * ((AKC ? BM * (BKS + 4) : BKS * BM) + (BKC ? BN * (BKS + 4) : BKS * BN));
 }
 
-// One output tile (or K-slice of one): the whole kernel body, as a device function of the workgroup index so that ONE launch
-// can work on two independent products (sgemm_pair below).
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
-__device__ __forceinline__ void sgemm_tile(const GemmArgs& g, const int bid, float* __restrict__ lds) {
-    constexpr int NT = WM * WN * KG * 64;
-    constexpr int BKS = BK * KG;                         // k-values staged per K-step
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(TM >= 1 && TN >= 1 && BK % 16 == 0 && (KG == 1 || KG == 2), "tile config");
-    constexpr int A_PITCH = AKC ? BKS + 4 : BM;          // floats per LDS row
-    constexpr int B_PITCH = BKC ? BKS + 4 : BN;
-    constexpr int A_TILE = AKC ? BM * A_PITCH : BKS * A_PITCH;
-    constexpr int B_TILE = BKC ? BN * B_PITCH : BKS * B_PITCH;
-    constexpr int A_ELEMS = BM * BKS / NT, B_ELEMS = BN * BKS / NT;   // floats staged per thread
-    static_assert(A_ELEMS % 4 == 0 && B_ELEMS % 4 == 0, "staging must divide into float4");
-
-    static_assert(2 * (A_TILE + B_TILE) == gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>(), "LDS size");
-    // buffer b: A tile at lds + b*(A_TILE+B_TILE), B tile right behind it
-    constexpr int BUF = A_TILE + B_TILE;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int kg = wave / (WM * WN), wl = wave % (WM * WN);          // K-group of this wave, wave inside the group
-    const int wm = wl / WN, wn = wl % WN;
-    const int kofs = kg * BK;                                        // its k offset inside a staged K-step
-    const int r = lane & 31, h = lane >> 5;
-    LG_TL(0);                                        // workgroup entered
-
-    // tile coordinates
-    const int id = xcd_remap(bid, g.nwg);
-    const int per_batch = g.tiles_m * g.tiles_n;
-    const int bs = g.div_per_batch.div(id);        // (batch, k-slice) pair
-    const int batch = g.div_slices.div(bs), slice = bs - batch * g.k_slices;
-    const int t = id - bs * per_batch;
-    // grouped order: consecutive ids walk GROUP_M tile rows before moving to the next tile column, so the
-    // ~64 workgroups resident on one XCD at a time cover a near-square patch of C and share both their
-    // A row-panels and their B column-panels in that XCD's 4 MiB L2
-    const int GROUP_M = g.group_m;
-    const int gspan = GROUP_M * g.tiles_n;
-    const int group = g.div_gspan.div(t);
-    const int first_m = group * GROUP_M, in_group = t - group * gspan;
-    const bool last_group = g.tiles_m - first_m < GROUP_M;
-    const int gsize = last_group ? g.tiles_m - first_m : GROUP_M;
-    const int tn = last_group ? g.div_last_group.div(in_group) : g.div_group.div(in_group);
-    const int tm = first_m + (in_group - tn * gsize);
-    const int64_t m0 = int64_t(tm) * BM, n0 = int64_t(tn) * BN;
-    const int b_outer = g.div_batch_inner.div(batch), b_inner = batch - b_outer * g.batch_inner;
-    const float* __restrict__ A = g.A + int64_t(b_outer) * g.sA + int64_t(b_inner) * g.sA2;
-    const float* __restrict__ B = g.B + int64_t(b_outer) * g.sB + int64_t(b_inner) * g.sB2;
-    float* __restrict__ C = g.C + int64_t(b_outer) * g.sC + int64_t(b_inner) * g.sC2;
-    const int64_t ldc = g.ldc;
-    const int accumulate = g.accumulate;
-    const float* __restrict__ bias = g.bias;
-    const int64_t k_begin = int64_t(slice) * g.k_per_slice;
-    const int64_t k_end = (k_begin + g.k_per_slice < g.K) ? k_begin + g.k_per_slice : g.K;
-    // the virtual ones-column (row sums of A) lives in column N of this workgroup's tile, if at all
-    const bool has_virtual = kHasExtras<BM, BN> && g.rowsum != nullptr && n0 <= g.N && g.N < n0 + BN;
-
-    // staging registers: a ring of PD K-tiles in flight between global memory and LDS (PD = 1: the tile fetched at the
-    // top of an iteration is written to LDS in its middle; small tiles have too few MFMAs per K-tile to cover the
-    // load latency that way and run PD = 2..3)
-    using StageA = std::conditional_t<VA, f32x4, float>;
-    using StageB = std::conditional_t<VB, f32x4, float>;
-    constexpr int A_CHUNKS = VA ? A_ELEMS / 4 : A_ELEMS, B_CHUNKS = VB ? B_ELEMS / 4 : B_ELEMS;
-    constexpr int NL = A_CHUNKS + B_CHUNKS;          // loads per thread and K-tile
-    static_assert((PD - 1) * NL + NL <= 63, "vmcnt is a 6-bit counter");
-    StageA ra_ring[PD][A_CHUNKS];
-    StageB rb_ring[PD][B_CHUNKS];
-
-    // Global -> register staging through buffer loads: the descriptor starts at the K-tile's first element (wave-uniform),
-    // the per-thread byte offsets are loop invariant, and every predicate (row / column beyond the matrix, k beyond the
-    // slice) turns the offset into one past the descriptor's range, for which the hardware returns 0 - no branches and
-    // no zero-fill moves in the K loop.
-    constexpr unsigned OOB = 0x80000000u;            // == num_records
-    unsigned offA[A_CHUNKS], offB[B_CHUNKS];
-    unsigned virt_mask = 0;                          // B chunks of this thread that start at the virtual column
-    int krem_ring[PD];                               // k extent of the tile waiting in each ring slot
-    int kcA[A_CHUNKS], kcB[B_CHUNKS];                // k coordinate of the chunk inside its K-tile
-#pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-        const int f = tid + i * NT;
-        int row, kk;                                  // row: index along M inside the tile, kk: index along K
-        if constexpr (VA) { if constexpr (AKC) { row = f / (BKS / 4); kk = (f % (BKS / 4)) * 4; } else { kk = f / (BM / 4); row = (f % (BM / 4)) * 4; } }
-        else              { if constexpr (AKC) { row = f / BKS; kk = f % BKS; } else { kk = f / BM; row = f % BM; } }
-        kcA[i] = kk;
-        // 32-bit on purpose: the host guarantees that a tile's farthest byte offset is below 2^31
-        const unsigned bytes = AKC ? (unsigned(row) * unsigned(g.lda) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.lda) + unsigned(row)) * 4u;
-        offA[i] = (m0 + row < g.M) ? bytes : OOB;
-    }
-#pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-        const int f = tid + i * NT;
-        int col, kk;
-        if constexpr (VB) { if constexpr (BKC) { col = f / (BKS / 4); kk = (f % (BKS / 4)) * 4; } else { kk = f / (BN / 4); col = (f % (BN / 4)) * 4; } }
-        else              { if constexpr (BKC) { col = f / BKS; kk = f % BKS; } else { kk = f / BN; col = f % BN; } }
-        kcB[i] = kk;
-        const unsigned bytes = BKC ? (unsigned(col) * unsigned(g.ldb) + unsigned(kk)) * 4u : (unsigned(kk) * unsigned(g.ldb) + unsigned(col)) * 4u;
-        offB[i] = (n0 + col < g.N) ? bytes : OOB;
-        if (has_virtual && n0 + col == g.N) virt_mask |= 1u << i;
-    }
-    const float* const Atile0 = AKC ? A + m0 * g.lda : A + m0;      // + k0 (AKC) / + k0 * lda per K-tile
-    const float* const Btile0 = BKC ? B + n0 * g.ldb : B + n0;
-
-    // The loads are inline asm so that the K loop can keep PD tiles in flight: hipcc's own wait insertion is
-    // conservative across the loop back-edge (it drains every outstanding load before the first LDS write).  The
-    // destination registers are NOT protected until wait_tile() below has run for that ring slot.
-    auto descriptor = [](const float* base) {
-        const unsigned long long p = reinterpret_cast<unsigned long long>(base);
-        u32x4 d;
-        d[0] = unsigned(p); d[1] = unsigned(p >> 32) & 0xffffu; d[2] = OOB; d[3] = 0x00020000u;
-        return d;
-    };
-    // tiles are requested strictly in order: running pointers instead of index arithmetic (every scalar instruction in
-    // the K loop of a lone small-tile workgroup shows up in its time)
-    const float* nextA = AKC ? Atile0 + k_begin : Atile0 + k_begin * g.lda;
-    const float* nextB = BKC ? Btile0 + k_begin : Btile0 + k_begin * g.ldb;
-    const int64_t stepA = AKC ? int64_t(BKS) : int64_t(BKS) * g.lda, stepB = BKC ? int64_t(BKS) : int64_t(BKS) * g.ldb;
-    const int nkt = int((k_end - k_begin + BKS - 1) / BKS);         // K-steps of this slice (32-bit: scalar compares in the loop)
-    const int last_krem = int(k_end - k_begin) - (nkt - 1) * BKS;    // k values of the last one
-    int requested = 0;
-    auto load_tile = [&](int slot) {
-        const int krem = requested == nkt - 1 ? last_krem : BKS;     // k values of this tile inside the slice
-        ++requested;
-        krem_ring[slot] = krem;
-        const u32x4 da = descriptor(nextA);
-        const u32x4 db = descriptor(nextB);
-        nextA += stepA;
-        nextB += stepB;
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const unsigned off = kcA[i] < krem ? offA[i] : OOB;
-            if constexpr (VA) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(ra_ring[slot][i]) : "v"(off), "s"(da));
-            else              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(ra_ring[slot][i]) : "v"(off), "s"(da));
-        }
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const unsigned off = kcB[i] < krem ? offB[i] : OOB;
-            if constexpr (VB) asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rb_ring[slot][i]) : "v"(off), "s"(db));
-            else              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(rb_ring[slot][i]) : "v"(off), "s"(db));
-        }
-    };
-    // wait until the loads of ring slot `slot` have landed, given that `younger` tiles were requested after it
-    auto wait_tile = [&](int slot, int younger) {
-        if (PD >= 3 && younger >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PD >= 3 ? 2 * NL : 0) : "memory");
-        else if (PD >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PD >= 2 ? NL : 0) : "memory");
-        else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) asm volatile("" : "+v"(ra_ring[slot][i]));
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) asm volatile("" : "+v"(rb_ring[slot][i]));
-    };
-
-    auto store_tile = [&](int buf, int slot) {
-        float* a = lds + buf * BUF;
-        float* b = lds + buf * BUF + A_TILE;
-        // K not a multiple of 4: the last float4 of a K-contiguous row runs into the next row - zero what lies beyond the
-        // slice (only the slice's last tile can be short)
-        if (g.k_tail && krem_ring[slot] < BKS) {
-            asm volatile("; short K tail" ::: "memory");        // keeps this rare fix-up a branch, not selects in every iteration
-            if constexpr (VA && AKC) {
-#pragma unroll
-                for (int i = 0; i < A_CHUNKS; ++i)
-#pragma unroll
-                    for (int e = 1; e < 4; ++e)
-                        if (kcA[i] + e >= krem_ring[slot]) ra_ring[slot][i][e] = 0.f;
-            }
-            if constexpr (VB && BKC) {
-#pragma unroll
-                for (int i = 0; i < B_CHUNKS; ++i)
-#pragma unroll
-                    for (int e = 1; e < 4; ++e)
-                        if (kcB[i] + e >= krem_ring[slot]) rb_ring[slot][i][e] = 0.f;
-            }
-        }
-        if constexpr (kHasExtras<BM, BN>) if (g.relu_a) {
-            asm volatile("; relu(A) on the way to LDS" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < A_CHUNKS; ++i) {
-                if constexpr (VA) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float x = ra_ring[slot][i][e]; ra_ring[slot][i][e] = (x != x) ? x : (x > 0.0f ? x : 0.0f); }
-                } else {
-                    const float x = ra_ring[slot][i]; ra_ring[slot][i] = (x != x) ? x : (x > 0.0f ? x : 0.0f);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int f = tid + i * NT;
-            if constexpr (VA) {
-                if constexpr (AKC) *reinterpret_cast<f32x4*>(a + (f / (BKS / 4)) * A_PITCH + (f % (BKS / 4)) * 4) = ra_ring[slot][i];
-                else               *reinterpret_cast<f32x4*>(a + (f / (BM / 4)) * A_PITCH + (f % (BM / 4)) * 4) = ra_ring[slot][i];
-            } else {
-                if constexpr (AKC) a[(f / BKS) * A_PITCH + (f % BKS)] = ra_ring[slot][i];
-                else               a[(f / BM) * A_PITCH + (f % BM)] = ra_ring[slot][i];
-            }
-        }
-        if constexpr (kHasExtras<BM, BN>) if (g.relu_b) {
-            asm volatile("; relu(B) on the way to LDS" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < B_CHUNKS; ++i) {
-                if constexpr (VB) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float x = rb_ring[slot][i][e]; rb_ring[slot][i][e] = (x != x) ? x : (x > 0.0f ? x : 0.0f); }
-                } else {
-                    const float x = rb_ring[slot][i]; rb_ring[slot][i] = (x != x) ? x : (x > 0.0f ? x : 0.0f);
-                }
-            }
-        }
-        if constexpr (kHasExtras<BM, BN>) if (has_virtual) {
-            // the loads returned zeros for the virtual column (beyond N): put the ones in, for the k values that exist
-#pragma unroll
-            for (int i = 0; i < B_CHUNKS; ++i) {
-                const bool virt = (virt_mask >> i) & 1u, kv = kcB[i] < krem_ring[slot];
-                const float one = kv ? 1.0f : 0.0f;
-                if constexpr (VB) {
-                    if constexpr (BKC) {                                                           // row N of B^T: ones along k
-                        if (virt) {
-                            const int kr = krem_ring[slot] - kcB[i];
-                            rb_ring[slot][i] = f32x4{kr > 0 ? 1.f : 0.f, kr > 1 ? 1.f : 0.f, kr > 2 ? 1.f : 0.f, kr > 3 ? 1.f : 0.f};
-                        }
-                    }
-                    else               { if (virt) rb_ring[slot][i] = f32x4{one, 0.f, 0.f, 0.f}; }     // k-row of B: column N, then beyond
-                } else {
-                    if (virt) rb_ring[slot][i] = one;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            const int f = tid + i * NT;
-            if constexpr (VB) {
-                if constexpr (BKC) *reinterpret_cast<f32x4*>(b + (f / (BKS / 4)) * B_PITCH + (f % (BKS / 4)) * 4) = rb_ring[slot][i];
-                else               *reinterpret_cast<f32x4*>(b + (f / (BN / 4)) * B_PITCH + (f % (BN / 4)) * 4) = rb_ring[slot][i];
-            } else {
-                if constexpr (BKC) b[(f / BKS) * B_PITCH + (f % BKS)] = rb_ring[slot][i];
-                else               b[(f / BN) * B_PITCH + (f % BN)] = rb_ring[slot][i];
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    auto compute_tile = [&](int buf, int kb_begin, int kb_end) {
-        const float* a = lds + buf * BUF + (AKC ? (wm * TM * 32 + r) * A_PITCH + 4 * h + kofs : (4 * h + kofs) * A_PITCH + wm * TM * 32 + r);
-        const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * TN * 32 + r) * B_PITCH + 4 * h + kofs : (4 * h + kofs) * B_PITCH + wn * TN * 32 + r);
-#pragma unroll
-        for (int kb = kb_begin; kb < kb_end; kb += 8) {
-            float fa[TM][4], fb[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (AKC) {
-                    const float4 v = *reinterpret_cast<const float4*>(a + i * 32 * A_PITCH + kb);
-                    fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) fa[i][s] = a[(kb + s) * A_PITCH + i * 32];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if constexpr (BKC) {
-                    const float4 v = *reinterpret_cast<const float4*>(b + j * 32 * B_PITCH + kb);
-                    fb[j][0] = v.x; fb[j][1] = v.y; fb[j][2] = v.z; fb[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) fb[j][s] = b[(kb + s) * B_PITCH + j * 32];
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // tile j waits in ring slot j % PD; tiles 0 .. PD-1 are requested up front
-#pragma unroll
-    for (int u = 0; u < PD; ++u)
-        if (u < nkt) load_tile(u);
-    {
-        const int younger = nkt - 1 < PD - 1 ? nkt - 1 : PD - 1;
-        wait_tile(0, younger);
-    }
-    store_tile(0, 0);
-    __syncthreads();
-    LG_TL(1);                                        // first K-tile in LDS
-    if constexpr (TM * TN == 1) {
-        // One accumulator per wave (small tiles: often ONE such wave per SIMD, nothing else to hide latency behind):
-        // the fragments of the next half K-tile are fetched from LDS while the MFMAs of the current half run.  The
-        // barrier sits between the halves: before it every wave has read ALL of tile kt and written its share of tile
-        // kt+1, after it the first-half fragments of tile kt+1 are fetched under the second half's MFMAs.
-        constexpr int HG = BK / 16;                  // k-groups of 8 per half tile
-        float fa[2][HG][4], fb[2][HG][4];
-        auto read_half = [&](int buf, int half, int slot) {
-            const float* a = lds + buf * BUF + (AKC ? (wm * 32 + r) * A_PITCH + 4 * h + kofs : (4 * h + kofs) * A_PITCH + wm * 32 + r);
-            const float* b = lds + buf * BUF + A_TILE + (BKC ? (wn * 32 + r) * B_PITCH + 4 * h + kofs : (4 * h + kofs) * B_PITCH + wn * 32 + r);
-#pragma unroll
-            for (int q = 0; q < HG; ++q) {
-                const int kb = half * (BK / 2) + q * 8;
-                if constexpr (AKC) {
-                    const float4 v = *reinterpret_cast<const float4*>(a + kb);
-                    fa[slot][q][0] = v.x; fa[slot][q][1] = v.y; fa[slot][q][2] = v.z; fa[slot][q][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fa[slot][q][e] = a[(kb + e) * A_PITCH];
-                }
-                if constexpr (BKC) {
-                    const float4 v = *reinterpret_cast<const float4*>(b + kb);
-                    fb[slot][q][0] = v.x; fb[slot][q][1] = v.y; fb[slot][q][2] = v.z; fb[slot][q][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fb[slot][q][e] = b[(kb + e) * B_PITCH];
-                }
-            }
-        };
-        auto mfma_part = [&](int slot, int q0, int q1) {
-#pragma unroll
-            for (int q = q0; q < q1; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][q][e], fb[slot][q][e], acc[0][0], 0, 0, 0);
-        };
-        auto mfma_half = [&](int slot) { mfma_part(slot, 0, HG); };
-        constexpr int HQ = HG > 1 ? HG / 2 : HG;     // MFMA groups issued before the LDS write of the next tile
-        read_half(0, 0, 0);
-        for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
-#pragma unroll
-            for (int u = 0; u < PD; ++u) {
-                const int kt = kt0 + u;
-                if (kt < nkt) {
-                    const int cur = kt & 1;
-                    if (PD == 1 && kt + 1 < nkt) load_tile(0);
-                    read_half(cur, 1, 1);
-                    // the LDS write of tile kt+1 goes in the MIDDLE of the dependent MFMA chain: its latency, and the
-                    // barrier's, then run under the MFMAs still queued instead of after the last one
-                    mfma_part(0, 0, HQ);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kt + 1 < nkt) {
-                        int younger = nkt - (kt + 2);
-                        if (younger > PD - 2) younger = PD - 2;
-                        wait_tile((u + 1) % PD, PD == 1 ? 0 : (younger < 0 ? 0 : younger));
-                        store_tile(cur ^ 1, (u + 1) % PD);
-                    }
-                    if (PD > 1 && kt + PD < nkt) load_tile(u);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_part(0, HQ, HG);
-                    __syncthreads();
-                    if (kt + 1 < nkt) read_half(cur ^ 1, 0, 0);
-                    mfma_half(1);
-                }
-            }
-        }
-    } else {
-        for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
-    #pragma unroll
-            for (int u = 0; u < PD; ++u) {
-                const int kt = kt0 + u;
-                if (kt < nkt) {
-                    const int cur = kt & 1;
-                    // PD == 1: tile kt+1 is requested here and written to LDS in the middle of this iteration.
-                    // PD  > 1: slot u (tile kt, in LDS since the last iteration) is refilled with tile kt + PD below, after
-                    //          the LDS write of tile kt+1 - whose loads were requested PD-1 iterations ago.
-                    if (PD == 1 && kt + 1 < nkt) load_tile(0);
-                    compute_tile(cur, 0, BK / 2);
-                    if (kt + 1 < nkt) {
-                        int younger = nkt - (kt + 2);                 // tiles kt+2 .. kt+PD-1 requested after tile kt+1
-                        if (younger > PD - 2) younger = PD - 2;
-                        wait_tile((u + 1) % PD, PD == 1 ? 0 : (younger < 0 ? 0 : younger));
-                        store_tile(cur ^ 1, (u + 1) % PD);                // ds_writes issue in the shadow of the second half's MFMAs
-                    }
-                    if (PD > 1 && kt + PD < nkt) load_tile(u);
-                    compute_tile(cur, BK / 2, BK);
-                    __syncthreads();
-                }
-            }
-        }
-    }
-
-    LG_TL(2);                                        // K loop done
-    if constexpr (KG == 2) {
-        // K-group 1 hands its accumulators to group 0 through LDS (the staging buffers are free after the loop's last
-        // barrier): slot (wave-in-group, accumulator, register) holds one value per lane, so both sides move 256 B per
-        // wave instruction without bank conflicts.  Group 1 is done after that.
-        float* x = lds + (wl * TM * TN * 16) * 64 + lane;
-        if (kg == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) x[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
-        }
-        __syncthreads();
-        if (kg == 1) return;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] += x[((i * TN + j) * 16 + e) * 64];
-    }
-    if constexpr (kCanSplitK<BM, BN, KG>) if (g.k_slices > 1) {
-        // split-K, folded inside the launch (cdna_hip_programming.md, in-launch split-K recipe, write-through form).
-        // Partial tiles go to the workspace in ACCUMULATOR layout - 16-byte piece ((i*TN + j)*4 + q) of thread tid at
-        // byte (((i*TN + j)*4 + q)*NT + tid)*16 of the (batch, slice, tile) slab - so stores and the fold move 1 KiB per
-        // wave instruction.  The slices of a tile run on different XCDs whose L2s are not coherent: slabs are stored
-        // write-through (sc1) and drained, ONE lane takes an agent-scope ticket, and the workgroup that arrives last
-        // reads every slab with sc1 loads (never served from a stale line), sums them in slice order - the same
-        // order in every run, so results are bit-reproducible - and runs the epilogue.  The ticket is reset for the
-        // next launch by that workgroup.
-        constexpr int SC1 = 16;                                   // aux bit of the raw buffer builtins
-        constexpr int TILE_BYTES = BM * BN * 4;
-        char* slab0 = reinterpret_cast<char*>(g.W) + (int64_t(batch) * g.k_slices * per_batch + t) * int64_t(TILE_BYTES);
-        const int64_t slice_stride = int64_t(per_batch) * TILE_BYTES;
-        {
-            const auto mine = __builtin_amdgcn_make_buffer_rsrc(slab0 + slice * slice_stride, 0, TILE_BYTES, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        u32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * q + e]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, mine, (((i * TN + j) * 4 + q) * NT + tid) * 16, 0, SC1);
-                    }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
-        __syncthreads();
-        LG_TL(3);                                                 // slab written and drained
-        int* arrived_last = reinterpret_cast<int*>(lds);          // the staging buffers are free after the K loop's last barrier
-        if (tid == 0) {
-            int* ticket = g.tickets + batch * per_batch + t;
-            const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = order == g.k_slices - 1;
-            if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *arrived_last = last;
-        }
-        __syncthreads();
-        LG_TL(4);                                                 // ticket drawn
-        if (!*arrived_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // no instruction: keeps the slab loads below the ticket
-        constexpr int CH = TM * TN >= 4 ? 1 : (TM * TN == 2 ? 2 : 4);     // slices whose loads are in flight together
-        for (int s0 = 0; s0 < g.k_slices; s0 += CH) {
-            u32x4 v[CH][TM * TN * 4];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int sl = s0 + c < g.k_slices ? s0 + c : s0;
-                const auto src = __builtin_amdgcn_make_buffer_rsrc(slab0 + sl * slice_stride, 0, TILE_BYTES, 0x00020000);
-#pragma unroll
-                for (int f = 0; f < TM * TN * 4; ++f) v[c][f] = __builtin_amdgcn_raw_buffer_load_b128(src, (f * NT + tid) * 16, 0, SC1);
-            }
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const bool live = s0 + c < g.k_slices, first = s0 + c == 0;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const float w = __uint_as_float(v[c][(i * TN + j) * 4 + e / 4][e % 4]);
-                            acc[i][j][e] = first ? w : (live ? acc[i][j][e] + w : acc[i][j][e]);
-                        }
-            }
-        }
-    }
-
-    LG_TL(5);                                        // slabs folded (or nothing to fold)
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t col = n0 + (wn * TN + j) * 32 + r;
-            const int64_t row0 = m0 + (wm * TM + i) * 32 + 4 * h;
-            const bool vcol = has_virtual && col == g.N;             // this lane holds row sums, not a column of C
-            if (col < g.N || vcol) {
-                const float bv = (bias && !vcol) ? bias[col] : 0.f;
-                float* const dst = vcol ? g.rowsum : C + col;
-                const int64_t dstride = vcol ? 1 : ldc;
-                const bool acc_flag = vcol ? g.rowsum_accumulate != 0 : accumulate != 0;
-                // The values first, the stores last, and the read-modify-write of `C += ...` in a block of its own:
-                // on gfx9-family hardware stores count in vmcnt like loads, so when the old-value loads sat in the same
-                // straight-line code as the stores, the wait in front of every add also drained the PREVIOUS store -
-                // 16 serialised store round trips, 2.0 of a 15.6 us launch (tools/gemm_timeline.py).
-                float val[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) val[e] = bias ? acc[i][j][e] + bv : acc[i][j][e];
-                if (acc_flag) {
-                    float old[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                        old[e] = row < g.M ? dst[row * dstride] : 0.f;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) val[e] = old[e] + val[e];
-                }
-                float* p = dst + row0 * dstride;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < g.M) p[((e & 3) + 8 * (e >> 2)) * dstride] = val[e];
-                }
-            }
-        }
-    }
-    LG_TL(6);                                        // epilogue stores issued
-}
-
+// The kernel body lives in gemm_tile_body.inc and is included textually: here as the whole kernel, and twice - once per
+// product - in the two-product launch below.
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
 __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>()];
-    sgemm_tile<BM, BN, BK, WM, WN, AKC, BKC, VA, VB, PD, KG>(g, blockIdx.x, lds);
+#define LG_TILE_OWNS_LDS 1
+#define LG_TILE_BID blockIdx.x
+#include "gemm_tile_body.inc"
+#undef LG_TILE_OWNS_LDS
+#undef LG_TILE_BID
 }
 
 // Two independent products in ONE launch: workgroups [0, first.nwg) work on the first, the rest on the second.  Made for the
@@ -662,8 +146,23 @@ template <int PD>
 __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, GemmArgs second) {
     constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, false, 1>();
     __shared__ __attribute__((aligned(16))) float lds[L1 > L2 ? L1 : L2];
-    if (int(blockIdx.x) < first.nwg) sgemm_tile<64, 64, 32, 2, 2, false, false, true, true, PD, 1>(first, blockIdx.x, lds);
-    else                             sgemm_tile<64, 64, 32, 2, 2, true, false, true, true, PD, 1>(second, int(blockIdx.x) - first.nwg, lds);
+    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
+    constexpr bool VA = true, VB = true, BKC = false;
+#define LG_TILE_OWNS_LDS 0
+    if (int(blockIdx.x) < first.nwg) {
+        constexpr bool AKC = false;
+        const GemmArgs& g = first;
+#define LG_TILE_BID int(blockIdx.x)
+#include "gemm_tile_body.inc"
+#undef LG_TILE_BID
+    } else {
+        constexpr bool AKC = true;
+        const GemmArgs& g = second;
+#define LG_TILE_BID (int(blockIdx.x) - first.nwg)
+#include "gemm_tile_body.inc"
+#undef LG_TILE_BID
+    }
+#undef LG_TILE_OWNS_LDS
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int KG>

@@ -135,7 +135,10 @@ class HipTensor(AbstractTensor):
         AbstractTensor.__init__(self, data=buffer, requires_grad=requires_grad)
         self._dtype = dtype if dtype.__class__ is np.dtype else np.dtype(dtype)
         self._shape = tuple(map(int, shape))
-        self._strides = contiguous_strides(self._shape) if strides is None else tuple(map(int, strides))
+        if strides is None:
+            self._strides, self._dense = contiguous_strides(self._shape), True
+        else:
+            self._strides, self._dense = tuple(map(int, strides)), None      # None: not looked at yet (is_contiguous)
         self._offset = int(offset)
         assert len(self._shape) == len(self._strides), \
             "Shapes and strides do not align! (%s <-> %s)" % (self._shape, self._strides)
@@ -352,12 +355,16 @@ class HipTensor(AbstractTensor):
         return self
 
     def is_contiguous(self) -> bool:
-        expect = 1
-        for s, st in zip(reversed(self._shape), reversed(self._strides)):
-            if s != 1 and st != expect:
-                return False
-            expect *= s
-        return True
+        dense = self._dense                  # shape and strides of a tensor object never change after construction ...
+        if dense is None:
+            dense, expect = True, 1
+            for s, st in zip(reversed(self._shape), reversed(self._strides)):
+                if s != 1 and st != expect:
+                    dense = False
+                    break
+                expect *= s
+            self._dense = dense
+        return dense
 
     def contiguous(self) -> "HipTensor":
         """self if already dense row-major, else a gathered copy (strided copy kernel)"""

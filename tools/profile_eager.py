@@ -1,28 +1,59 @@
-"""cProfile of the eager MLP training step on the GPU box: where does the host time go?"""
-import cProfile, pstats, os, sys, io
+"""cProfile of the eager (python tape every step) MLP training step: where the host time goes.
+    python tools/profile_eager.py [steps]"""
+import cProfile
+import os
+import pstats
+import sys
 import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import lightgrad_amd as light
-from lightgrad_amd import HipTensor
-from lightgrad_amd.autograd.hip import HipDevice
+import lightgrad_amd as light                                   # noqa: E402
+from lightgrad_amd import HipTensor                              # noqa: E402
+from lightgrad_amd.autograd.hip import HipDevice                 # noqa: E402
+from lightgrad_amd.dist import SingleProcess, DataParallel       # noqa: E402
+
 
 class MLP(light.nn.Module):
     def __init__(self):
         light.nn.Module.__init__(self)
-        self.l1 = light.nn.Linear(784, 512); self.l2 = light.nn.Linear(512, 10)
+        self.l1, self.l2 = light.nn.Linear(784, 512), light.nn.Linear(512, 10)
+
     def forward(self, x):
         return self.l2(self.l1(x.reshape(-1, 784)).relu())
+
+
 np.random.seed(0)
 model = MLP().map_parameters(lambda p: p.hip())
-opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=True)
+dp = DataParallel(model.parameters(), SingleProcess(), flatten=True)
+opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=True, device_step=True)
+dp.attach(opt)
 x = HipTensor.from_numpy(np.random.uniform(0, 1, (1024, 784)).astype(np.float32))
 t = HipTensor.from_numpy(np.eye(10, dtype=np.float32)[np.random.randint(0, 10, 1024)])
+
+
 def step():
-    l = light.loss.mse(model(x), t); opt.zero_grad(); l.backward(); opt.step(); return l
-for _ in range(20): step()
+    loss = light.loss.mse(model(x), t)
+    opt.zero_grad()
+    loss.backward()
+    dp.sync_gradients()
+    opt.step()
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+for _ in range(50):
+    step()
 HipDevice.synchronize()
-pr = cProfile.Profile(); pr.enable()
-for _ in range(300): step()
+import time
+t0 = time.perf_counter()
+for _ in range(n):
+    step()
 HipDevice.synchronize()
+print("%.1f us per eager step (un-profiled)" % (1e6 * (time.perf_counter() - t0) / n))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(n):
+    step()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+HipDevice.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)

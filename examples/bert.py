@@ -6,7 +6,8 @@ examples/bert.py:14-229; its tokenizer and `from_pretrained` need network access
 Differences from the reference, on purpose:
   * embeddings are looked up with `weight[ids]` on the tensor's own backend (the reference round-trips
     through the CPU and thereby drops the embedding gradient, bert.py:19-21);
-  * `gelu` uses the backend's fused op when there is one (same expression, bert.py:12).
+  * `gelu` uses the backend's fused op when there is one (same expression, bert.py:12); so does the scaling of the
+    attention scores in front of their softmax (bert.py:81-86) when there is no mask to add in between.
 
     python examples/bert.py [--cpu] [--batch 8]        # forward + backward of a random tiny-BERT
 """
@@ -78,12 +79,17 @@ class BertSelfAttention(nn.Module):
         q = self.query(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
         k = self.key(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 3, 1)
         v = self.value(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
-        scores = q @ k / math.sqrt(self.d)
-        if attention_mask is not None:
-            # (b, s) -> (b, 1, 1, s); for batch 1 this is the reference's (1, 1, 1, s) (bert.py:82, which breaks for b > 1)
-            mask = attention_mask.reshape(attention_mask.shape[0], 1, 1, attention_mask.shape[1])
-            scores = scores + ((1.0 - mask) * -10000.0).detach()
-        probs = scores.softmax(axis=-1)
+        scores = q @ k
+        if attention_mask is None and hasattr(scores, "scaled_softmax"):
+            # the backend's one-kernel form of the two lines below: the same x * sqrt(d)**-1, rounded to fp32, then softmax
+            probs = scores.scaled_softmax(math.sqrt(self.d) ** -1)
+        else:
+            scores = scores / math.sqrt(self.d)
+            if attention_mask is not None:
+                # (b, s) -> (b, 1, 1, s); for batch 1 this is the reference's (1, 1, 1, s) (bert.py:82, which breaks for b > 1)
+                mask = attention_mask.reshape(attention_mask.shape[0], 1, 1, attention_mask.shape[1])
+                scores = scores + ((1.0 - mask) * -10000.0).detach()
+            probs = scores.softmax(axis=-1)
         context = (probs @ v).transpose(0, 2, 1, 3).reshape(b, s, self.h * self.d)
         return context, probs
 

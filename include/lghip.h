@@ -349,6 +349,11 @@ int lg_mse_bump_f32(const float* y, const float* y_hat, float* err, float* loss,
  * which returns dx only (dw = sum_rows(g * xhat), db = sum_rows(g) are lg_ew + lg_reduce calls). */
 int lg_softmax_f32(const float* x, float* y, int64_t rows, int64_t cols);
 int lg_softmax_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols);
+/* softmax(x * scale) and its backward (dx of the UNSCALED x) - attention's `(q @ k / sqrt(d)).softmax(-1)` (reference
+ * examples/bert.py:81-86) without the separate scaling passes; x * scale is rounded to fp32 before anything else, and the
+ * backward multiplies the finished fp32 gradient, so both give the bits of the two-kernel form. */
+int lg_softmax_scaled_f32(const float* x, float* y, int64_t rows, int64_t cols, float scale);
+int lg_softmax_scaled_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols, float scale);
 int lg_layernorm_f32(const float* x, const float* w, const float* b, float* y, float* xhat, float* rstd,
                      int64_t rows, int64_t cols, double eps);
 int lg_layernorm_bwd_f32(const float* g, const float* w, const float* xhat, const float* rstd, float* dx,

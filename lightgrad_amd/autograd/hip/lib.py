@@ -95,6 +95,8 @@ PROTOTYPES = {
     "lg_mse_finalize_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "lg_softmax_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64]),
     "lg_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_softmax_scaled_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
+    "lg_softmax_scaled_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),
     "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_cross_entropy_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64]),

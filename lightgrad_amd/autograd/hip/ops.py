@@ -293,13 +293,52 @@ def _collapse_batch(shape, strides):
     return n, st
 
 
-def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=False):
+def _dense_permutation(shape, strides) -> bool:
+    """do `strides` address a dense block of prod(shape) elements, each exactly once (a stride-permuted dense tensor)?"""
+    expect = 1
+    for extent, stride in sorted(((e, st) for e, st in zip(shape, strides) if e != 1), key=lambda d: d[1]):
+        if stride != expect:
+            return False
+        expect *= extent
+    return True
+
+
+def _layout_like(t):
+    """strides for a fresh tensor of t's shape laid out in memory like t - when t is a stride-permuted dense tensor (the head
+    split `(b, s, h*d) -> (b, h, s, d)` of attention) that a GEMM can store into (one of the last two dims has stride 1);
+    None for dense t (nothing to imitate) and for anything else"""
+    if len(t._shape) < 2 or t.is_contiguous() or not _dense_permutation(t._shape, t._strides):
+        return None
+    if not (t._strides[-1] == 1 or t._shape[-1] == 1 or t._strides[-2] == 1 or t._shape[-2] == 1):
+        return None
+    return t._strides
+
+
+def _product_layout(a, b, out_shape):
+    """Memory layout for a @ b when the right operand is a head-split view with rows of N contiguous values - `probs @ v`
+    with v = (b, s, h*d) seen as (b, h, s, d): the product takes v's nesting of batch and row dims, (b, s_q, h, d) in memory,
+    so that the `transpose(0, 2, 1, 3).reshape(b, s, h*d)` that follows (bert.py:87) is a view instead of a copy.  None: dense."""
+    if len(b._shape) < 3 or a._shape[:-2] != b._shape[:-2] or b._strides[-1] != 1 or b.is_contiguous() \
+            or not _dense_permutation(b._shape, b._strides):
+        return None
+    # dims of b ordered from the innermost in memory; the product's dim -2 (M) takes the place of b's dim -2 (K)
+    order = sorted(range(len(b._shape)), key=lambda i: (b._strides[i], -i))
+    strides, run = [0] * len(out_shape), 1
+    for i in order:
+        strides[i] = run
+        run *= out_shape[i]
+    return tuple(strides)
+
+
+def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=False, out_strides=None):
     """a (..., M, K) @ b (..., K, N) [+ bias (N,)] -> (..., M, N) on the MFMA SGEMM kernel.
 
     Operands are consumed in place whenever one of their last two dims has stride 1
     (row-major or stride-permuted views alike).  `out_colmajor` stores the result
-    transposed in memory and returns the matching view, so that a gradient can be
-    produced directly in the layout of the tensor it belongs to.
+    transposed in memory and returns the matching view, `out_strides` (a dense permutation
+    with a unit stride among the last two dims, see _layout_like) stores it in any such
+    layout - so that a gradient can be produced directly in the layout of the tensor it
+    belongs to and an attention product in the layout its consumer reshapes for free.
     """
     _require_f32(a, b)
     squeeze_a = squeeze_b = False
@@ -315,6 +354,7 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
 
     # (B..., M, K) @ (K, N) with dense leading dims is ONE tall GEMM
     if len(b._shape) == 2 and len(a._shape) > 2:
+        assert out_strides is None
         lead = _collapse_batch(a._shape[:-1], a._strides[:-1])
         if lead is None or not (a._strides[-1] == 1 or K == 1):
             a = a.contiguous()
@@ -330,60 +370,78 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
     for s in batch_shape:
         nb *= s
     out_shape = batch_shape + (M, N)
+    dense = contiguous_strides(out_shape)
+    if out_colmajor:
+        assert out_strides is None
+        out_strides = dense[:-2] + (1, M)
+    if out_strides is not None and tuple(out_strides) == dense:
+        out_strides = None
     if accumulate_into is not None:
         # C += A @ B straight into an existing dense buffer (a parameter's gradient): no temporary, no add pass
-        assert not out_colmajor and bias is None and not batch_shape
+        assert out_strides is None and bias is None and not batch_shape
         assert accumulate_into._shape == out_shape and accumulate_into.is_contiguous() and accumulate_into._dtype == _F32
         flush_lazy_readers(accumulate_into)
         out = accumulate_into
-    elif out_colmajor:
-        out = HipTensor.empty(batch_shape + (N, M))
+    elif out_strides is not None:
+        assert bias is None and not (squeeze_a or squeeze_b) and len(out_strides) == len(out_shape)
+        assert _dense_permutation(out_shape, out_strides), "matmul: output layout %s is not a dense permutation of %s" % (out_strides, out_shape)
+        out = HipTensor(HipBuffer(nb * M * N * 4), out_shape, tuple(out_strides), 0, _F32)
     else:
         out = HipTensor.empty(out_shape)
+    # how the kernel stores one (M, N) result: rows of N with ldc between them, or - for a layout whose M index is the
+    # contiguous one - the transposed product C^T = B^T @ A^T as rows of M
+    s_m, s_n = out._strides[-2], out._strides[-1]
+    if N == 1 or s_n == 1:
+        t_store, ldc = False, (s_m if M > 1 else N)
+    else:
+        assert M == 1 or s_m == 1, "matmul: output layout needs a unit stride among its last two dims"
+        t_store, ldc = True, (s_n if N > 1 else M)
+    assert ldc >= (M if t_store else N)
 
     def batch_layout(t):
         bs = _bstrides(HipTensor(t.data, t._shape[:-2], t._strides[:-2], t._offset, t._dtype), batch_shape) if batch_shape else ()
         return bs
 
     sa, sb = batch_layout(a), batch_layout(b)
-    so = contiguous_strides(batch_shape + (1,))[:-1] if batch_shape else ()
-    so = tuple(s * M * N for s in so)
+    so = tuple(out._strides[:-2])
 
     L = _l.lib()
 
     if bias is not None:
-        assert not out_colmajor and bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32
+        assert not t_store and bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32
 
     def launch(pa, pb, po, count, stra, strb, stro):
         if bias is not None:
             _l.check(L.lg_gemm_bias_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
-                                        pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count, bias.ptr))
-        elif out_colmajor:
+                                        pa, ma.ld, stra, pb, mb.ld, strb, po, ldc, stro, count, bias.ptr))
+        elif t_store:
             # C^T (N x M, row-major) = B^T @ A^T : swap the operands and flip their layouts
             _l.check(L.lg_gemm_f32(0 if mb.colmajor else 1, 0 if ma.colmajor else 1, N, M, K,
-                                   pb, mb.ld, strb, pa, ma.ld, stra, po, M, stro, count, 0))
+                                   pb, mb.ld, strb, pa, ma.ld, stra, po, ldc, stro, count, 0))
         else:
             _l.check(L.lg_gemm_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
-                                   pa, ma.ld, stra, pb, mb.ld, strb, po, N, stro, count,
+                                   pa, ma.ld, stra, pb, mb.ld, strb, po, ldc, stro, count,
                                    1 if (accumulate_into is not None and not overwrite) else 0))
 
     if nb > 0 and M > 0 and N > 0:
-        ca, cb = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb)
-        if ca is not None and cb is not None:
-            launch(a.ptr, b.ptr, out.ptr, nb, ca[1], cb[1], M * N)
-        elif (bias is None and len(batch_shape) >= 2
-              and _collapse_batch(batch_shape[:-1], sa[:-1]) is not None and _collapse_batch(batch_shape[:-1], sb[:-1]) is not None):
+        ca, cb, co = _collapse_batch(batch_shape, sa), _collapse_batch(batch_shape, sb), _collapse_batch(batch_shape, so)
+        outer = None
+        if bias is None and len(batch_shape) >= 2:
+            outer = [_collapse_batch(batch_shape[:-1], st[:-1]) for st in (sa, sb, so)]
+        if ca is not None and cb is not None and co is not None:
+            launch(a.ptr, b.ptr, out.ptr, nb, ca[1], cb[1], co[1])
+        elif outer is not None and None not in outer:
             # attention after the head split: (batch, head) do not walk as ONE stride, but as two - still one launch
-            (n_outer, a_outer), (_, b_outer) = _collapse_batch(batch_shape[:-1], sa[:-1]), _collapse_batch(batch_shape[:-1], sb[:-1])
+            (n_outer, a_outer), (_, b_outer), (_, o_outer) = outer
             inner = batch_shape[-1]
-            if out_colmajor:      # C^T = B^T @ A^T, as in launch()
+            if t_store:      # C^T = B^T @ A^T, as in launch()
                 _l.check(L.lg_gemm_batched2_f32(0 if mb.colmajor else 1, 0 if ma.colmajor else 1, N, M, K,
                                                 b.ptr, mb.ld, b_outer, sb[-1], a.ptr, ma.ld, a_outer, sa[-1],
-                                                out.ptr, M, inner * M * N, M * N, n_outer, inner, 0))
+                                                out.ptr, ldc, o_outer, so[-1], n_outer, inner, 0))
             else:
                 _l.check(L.lg_gemm_batched2_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
                                                 a.ptr, ma.ld, a_outer, sa[-1], b.ptr, mb.ld, b_outer, sb[-1],
-                                                out.ptr, N, inner * M * N, M * N, n_outer, inner, 0))
+                                                out.ptr, ldc, o_outer, so[-1], n_outer, inner, 0))
         else:
             # batch dims that do not collapse at all: loop over the leading dims, batch the innermost one
             inner = batch_shape[-1]
@@ -391,11 +449,7 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
                 oa = _py.sum(i * s for i, s in zip(idx, sa[:-1])) * 4
                 ob = _py.sum(i * s for i, s in zip(idx, sb[:-1])) * 4
                 oo = _py.sum(i * s for i, s in zip(idx, so[:-1])) * 4
-                launch(a.ptr + oa, b.ptr + ob, out.ptr + oo, inner, sa[-1], sb[-1], M * N)
-    if out_colmajor:
-        nd = len(out_shape)
-        out = HipTensor(out.data, out_shape, out._strides[:-2] + (1, M), out._offset, out._dtype)
-        assert nd == len(out._strides)
+                launch(a.ptr + oa, b.ptr + ob, out.ptr + oo, inner, sa[-1], sb[-1], so[-1])
     if squeeze_a:
         out = out.reshape(*out._shape[:-2], out._shape[-1])
     if squeeze_b:
@@ -476,6 +530,8 @@ class dot(Function):
     nn.Linear gets a gradient that transposes back to a dense dW without a strided accumulate. """
     def forward(ctx, a, b):
         ctx.save_for_backward(a, b)
+        if len(a._shape) > 2 and len(b._shape) > 2:
+            return _gemm(a, b, out_strides=_product_layout(a, b, _broadcast_shapes(a._shape[:-2], b._shape[:-2]) + (a._shape[-2], b._shape[-1])))
         return _gemm(a, b)
 
     def backward(ctx, out_grad):
@@ -507,10 +563,15 @@ class dot(Function):
                 _gemm(_swap_last(a), out_grad, accumulate_into=acc_b, overwrite=b._consume_zero_pending())
                 b._notify_grad_written()
                 gb = False
+        # each gradient in the memory layout of the operand it belongs to (a head-split view, a transposed matrix): the
+        # transpose / reshape backward that follow are then views, not gathered copies
+        same_batch = a._shape[:-2] == b._shape[:-2] == out_grad._shape[:-2]
         if ga is None:
-            ga = _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
+            like = _layout_like(a) if same_batch else None
+            ga = _gemm(out_grad, _swap_last(b), out_strides=like) if like is not None else _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
         if gb is None:
-            gb = _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
+            like = _layout_like(b) if same_batch else None
+            gb = _gemm(_swap_last(a), out_grad, out_strides=like) if like is not None else _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
         return (None if ga is False else ga), (None if gb is False else gb)
 
 
@@ -1025,6 +1086,15 @@ class linear(Function):
         if pre is not None and x._shape[0] > 0:
             # x = relu(pre) that nobody has looked at yet: the GEMM reads pre and applies the relu while staging it
             return _gemm_fused(pre, _swap_last(weight), bias=bias, relu_a=True)[0]
+        if bias is None and pre is None and x._dtype == _F32 and weight._dtype == _F32 and len(x._shape) >= 1 \
+                and x._shape[-1] > 0 and x.numel() // x._shape[-1] * weight._shape[0] >= _LAZY_LINEAR_MIN_OUT:
+            # a large bias-free product (BERT's decoder onto the vocabulary): wait and see whether a bias row is added to it
+            # next (`decoder(h) + bias`, reference bert.py:227) - HipTensor.add then runs ONE GEMM with the bias in
+            # its epilogue instead of a second pass over the (rows, vocabulary) result
+            out = HipTensor(None, x._shape[:-1] + (weight._shape[0],), None, 0, _F32)
+            out._lazy_source = ("linear", x, weight)
+            out._watch_sources(x, weight)
+            return out
         return _gemm(x, _swap_last(weight), bias=bias)
 
     def backward(ctx, out_grad):
@@ -1059,7 +1129,7 @@ class linear(Function):
     @staticmethod
     def _backward_products(x, x2, weight, bias, has_bias, want_db, g2):
         dw = dx = db = None
-        if weight.requires_grad and want_db and g2._shape[0] > 0:
+        if weight.requires_grad and want_db and g2._shape[0] > 0 and _rowsum_column_is_cheap(weight._shape[0], weight._shape[1]):
             # dW and db from one launch: db = column sums of g = row sums of g^T, a virtual extra column of the product
             acc_w, acc_b = weight._grad_accumulator(), bias._grad_accumulator()
             acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
@@ -1140,6 +1210,36 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
 
 
 linear._backward_through_lazy_relu = staticmethod(_linear_backward_through_lazy_relu)
+
+
+_LAZY_LINEAR_MIN_OUT = 1 << 20      # elements of the product from which a bias-free Linear waits for its consumer
+
+
+_tape_add = HipTensor.add
+
+
+def _add_folding_bias(self, other):
+    """`a + b`.  Peephole: a = x @ W^T of a bias-free Linear that nobody has looked at yet (lazy, see linear.forward) and b one
+    value per output feature -> a single `linear` node over (x, W, b), the bias added in the GEMM epilogue.  Same values (the
+    product is rounded to fp32 before the bias is added) and the same gradients for x, W and b as the two-node form; should `a`
+    be used elsewhere too, its own node still carries that use."""
+    src = self._lazy_source
+    if (src is not None and self._data is None and src[0] == "linear" and other.__class__ is HipTensor
+            and other._shape == self._shape[-1:] and other._dtype == _F32 and other.is_contiguous()):
+        return linear(src[1], src[2], other)
+    return _tape_add(self, other)
+
+
+_add_folding_bias.__name__ = "add"
+HipTensor.add = _add_folding_bias
+
+
+def _rowsum_column_is_cheap(out_features: int, in_features: int) -> bool:
+    """db rides in the dW GEMM as a virtual extra column of the (out_features, in_features) product.  That is free when the
+    last 64-wide tile column is partial anyway, and harmless while the whole grid fits the chip in one round; a full extra tile
+    column on a throughput-bound product (BERT's decoder: 477 x 2 -> 477 x 3 tiles) costs more than a reduction of its own."""
+    tiles_m, tiles_n = -(-out_features // 64), -(-(in_features + 1) // 64)
+    return in_features % 64 != 0 or tiles_m * tiles_n <= 256
 
 
 def _head_eligible(x, weight, bias) -> bool:
@@ -1238,7 +1338,7 @@ def _rows_view(t):
 @HipTensor.register_op(overwrite=True)
 class softmax(Function):
     """ row-wise fused softmax (composite: autograd/ops.py:62-66: exp(t - max) * (sum ** -1)); any axis is moved last """
-    def forward(ctx, t, axis=-1):
+    def forward(ctx, t, axis=-1, scale=1.0):
         _require_f32(t)
         nd = len(t._shape)
         axis = axis % nd
@@ -1248,8 +1348,8 @@ class softmax(Function):
             t = t.transpose(*perm)
         x, rows, cols = _rows_view(t)
         y = HipTensor.empty(x._shape)
-        _l.check(_l.lib().lg_softmax_f32(x.ptr, y.ptr, rows, cols))
-        ctx.save_for_backward(y, perm)
+        _l.check(_l.lib().lg_softmax_scaled_f32(x.ptr, y.ptr, rows, cols, float(scale)))
+        ctx.save_for_backward(y, perm, float(scale))
         if perm is not None:
             inv = [0] * nd
             for i, j in enumerate(perm):
@@ -1258,17 +1358,26 @@ class softmax(Function):
         return y
 
     def backward(ctx, out_grad):
-        y, perm = ctx.get_saved_tensors()
+        y, perm, scale = ctx.get_saved_tensors()
         g = out_grad.transpose(*perm) if perm is not None else out_grad
         g, rows, cols = _rows_view(g)
         dx = HipTensor.empty(y._shape)
-        _l.check(_l.lib().lg_softmax_bwd_f32(y.ptr, g.ptr, dx.ptr, rows, cols))
+        _l.check(_l.lib().lg_softmax_scaled_bwd_f32(y.ptr, g.ptr, dx.ptr, rows, cols, scale))
         if perm is not None:
             inv = [0] * len(perm)
             for i, j in enumerate(perm):
                 inv[j] = i
             dx = dx.transpose(*inv)
         return dx
+
+
+def _scaled_softmax(t, scale, axis=-1):
+    """softmax(t * scale) in one kernel forward, one backward (attention scores: reference examples/bert.py:81-86 spells it
+    `(q @ k / sqrt(d)).softmax(-1)`, three kernels each way); same bits as `(t * scale).softmax(axis)` on this backend"""
+    return softmax(t, axis=axis, scale=scale)
+
+
+HipTensor.scaled_softmax = _scaled_softmax
 
 
 @HipTensor.register_op()

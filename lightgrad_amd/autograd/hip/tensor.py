@@ -166,6 +166,8 @@ class HipTensor(AbstractTensor):
     #   ("head", x, relu, weight, bias)  created by linear.forward for a skinny output layer (<= 16 features):
     #                                    act(x) @ weight^T + bias, act = relu if `relu` else identity; loss.mse computes
     #                                    it together with the loss in one launch (csrc/head.hip)
+    #   ("linear", x, weight)            created by linear.forward for a large bias-free product x @ weight^T: `+ bias` right
+    #                                    after it becomes the GEMM's bias epilogue (ops._add_folding_bias)
     #   ("mse_rows", row_loss, n)        the scalar loss of that launch: (sum(row_loss) * (1/n)) * 0.5.  The backward
     #                                    launch of the head finishes it with a spare workgroup; reading it earlier costs
     #                                    one small launch (lg_mse_finalize_f32)
@@ -202,6 +204,9 @@ class HipTensor(AbstractTensor):
             _, row_loss, n = self._lazy_source
             out = HipTensor.empty((), requires_grad=False)
             _l.check(_l.lib().lg_mse_finalize_f32(row_loss.ptr, row_loss.numel(), n, out.ptr))
+        elif kind == "linear":
+            _, x, weight = self._lazy_source
+            out = _ops._gemm(x, _ops._swap_last(weight))
         else:
             assert kind == "head"
             _, x, relu, weight, bias = self._lazy_source

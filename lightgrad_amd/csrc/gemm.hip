@@ -431,7 +431,12 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
             };
             const double c256 = fused_extras ? 1e300 : cost(256, 256, 0.88), c128 = cost(128, 128, 0.74), c64 = cost(64, 64, 0.85);
             tile = (c256 <= c128 && c256 <= c64) ? 2 : (c128 <= c64 ? 0 : 9);
-            if (tile == 9 && batch == 1) {
+            // inside a pair bracket the 64x64 tile stays: only it can share a launch, and for the small products of a
+            // transformer layer's Linear backward that is worth more than the K-group tile (tiny-BERT, 12 Linear layers:
+            // 0.980 -> 0.901 ms per forward+backward).  LG_GEMM_PAIR_KG=1 (experiments) lets the K-group tile win again.
+            static const char* pair_kg_env = getenv("LG_GEMM_PAIR_KG");
+            const bool keep_for_pair = lg::pair_state().active == 1 && !(pair_kg_env && atoi(pair_kg_env) == 1);
+            if (tile == 9 && batch == 1 && !keep_for_pair) {
                 // Too few 64x64 tiles to fill the chip: split K across workgroups (slabs + ticket + fold) or INSIDE a workgroup
                 // on a half-size tile (64x32 / 32x64 with two K-groups, one LDS exchange)?  Same model as launch_config (us):
                 // K-steps x time per step (+ hand-off), constants from tools/gemm_timeline.py - a K-group step stages 64 k and

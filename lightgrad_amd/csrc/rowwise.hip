@@ -31,7 +31,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // one wave per row; 4 rows per 256-thread block
 // REGS = floats per lane kept in registers (row length <= 64 * REGS); 0 = strided loops that re-read the row
 template <int REGS>
-__global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t cols) {
+__global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int64_t cols, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -44,11 +44,11 @@ __global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, 
 #pragma unroll
         for (int k = 0; k < REGS; ++k) {
             const int64_t c = lane + 64 * k;
-            v[k] = c < cols ? xr[c] : -INFINITY;
+            v[k] = c < cols ? xr[c] * scale : -INFINITY;        // softmax(x * scale): the product rounded to fp32 first, like the two-op form
             m = (v[k] > m || v[k] != v[k]) ? v[k] : m;
         }
     } else {
-        for (int64_t c = lane; c < cols; c += 64) { const float t = xr[c]; m = (t > m || t != t) ? t : m; }
+        for (int64_t c = lane; c < cols; c += 64) { const float t = xr[c] * scale; m = (t > m || t != t) ? t : m; }
     }
     m = wave_max(m);
     float s = 0.f;
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, 
             s += v[k];
         }
     } else {
-        for (int64_t c = lane; c < cols; c += 64) s += expf(xr[c] + (-m));
+        for (int64_t c = lane; c < cols; c += 64) s += expf(xr[c] * scale + (-m));
     }
     s = wave_sum(s);
     const float inv = 1.0f / s;
@@ -71,11 +71,11 @@ __global__ void __launch_bounds__(256) softmax_fwd(const float* __restrict__ x, 
             if (c < cols) yr[c] = v[k] * inv;
         }
     } else {
-        for (int64_t c = lane; c < cols; c += 64) yr[c] = expf(xr[c] + (-m)) * inv;
+        for (int64_t c = lane; c < cols; c += 64) yr[c] = expf(xr[c] * scale + (-m)) * inv;
     }
 }
 
-// dx = y * (g - sum(g * y) / sum(y)).  The shift sum(g*y) is formed, divided by sum(y) (1 up to the rounding of y) and
+// dx = y * (g - sum(g * y) / sum(y)) [* scale, for softmax(x * scale)].  The shift sum(g*y) is formed, divided by sum(y) (1 up to the rounding of y) and
 // subtracted in DOUBLE: every row of dx must sum to zero, and consumers rely on it - the query / key gradients of
 // attention are d(scores) @ k and d(scores)^T @ q with k, q nearly constant along the summed axis at initialisation, a
 // contraction that cancels everything EXCEPT the row sums of d(scores) (condition ~150 on tiny-BERT).  With an fp32 shift
@@ -89,7 +89,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 __global__ void __launch_bounds__(256) softmax_bwd(const float* __restrict__ y, const float* __restrict__ g, float* __restrict__ dx,
-                                                   int64_t rows, int64_t cols) {
+                                                   int64_t rows, int64_t cols, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) softmax_bwd(const float* __restrict__ y, 
     dot = wave_sum_f64(dot);
     norm = wave_sum_f64(norm);
     const double shift = dot / norm;
-    for (int64_t c = lane; c < cols; c += 64) dr[c] = float(double(yr[c]) * (double(gr[c]) - shift));
+    for (int64_t c = lane; c < cols; c += 64) dr[c] = float(double(yr[c]) * (double(gr[c]) - shift)) * scale;
 }
 
 // ---- LayerNorm over the last axis ---------------------------------------------------------------------
@@ -296,6 +296,75 @@ __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restric
     }
 }
 
+// wide rows that fit the REGISTERS of one 1024-thread workgroup (cols <= 1024 * PER): the row is read from memory once -
+// maximum, exp and sum work on the held values (numpy's own order of operations: max, exp(x - max), sum, divide) and the
+// gradient is written straight from them.  BERT's (1024, 30522) logits: 83.6 -> see profiles/README.md r2.
+template <typename LabelT, int PER>
+__global__ void __launch_bounds__(1024) cross_entropy_held(const float* __restrict__ x, const LabelT* __restrict__ labels,
+                                                           float* __restrict__ dlogits, float* __restrict__ nll, int64_t cols,
+                                                           float inv_rows, int* status) {
+    __shared__ float red_m[16], red_s[16];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + row * cols;
+    const int ncols = int(cols);                 // <= 1024 * PER
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = i * 1024 + tid;
+        v[i] = c < ncols ? xr[c] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) m = (v[i] > m || v[i] != v[i]) ? v[i] : m;
+    m = wave_max(m);
+    if (lane == 0) red_m[wave] = m;
+    __syncthreads();
+    float M = red_m[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = (red_m[w] > M || red_m[w] != red_m[w]) ? red_m[w] : M;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = i * 1024 + tid;
+        v[i] = c < ncols ? expf(v[i] + (-M)) : 0.f;
+        s += v[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) S += red_s[w];
+    const float inv = 1.0f / S;
+    int64_t label = int64_t(labels[row]);
+    if (label < 0) label += cols;
+    if (label < 0 || label >= cols) {
+        if (tid == 0) { nll[row] = __builtin_nanf(""); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
+    const int ilabel = (label < 0 || label >= cols) ? -1 : int(label);
+    float* dr = dlogits + row * cols;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = i * 1024 + tid;
+        if (c < ncols) {
+            const float p = v[i] * inv;
+            dr[c] = (c == ilabel ? p - 1.0f : p) * inv_rows;
+            if (c == ilabel) nll[row] = -logf(p);
+        }
+    }
+}
+
+template <typename LabelT>
+static void launch_cross_entropy_held(const float* logits, const LabelT* labels, float* dlogits, float* nll, int64_t rows, int64_t cols,
+                                      float inv_rows) {
+    const dim3 grid{unsigned(rows)}, block(1024);
+    hipStream_t s = rt().stream;
+    if (cols <= 1024 * 8)       hipLaunchKernelGGL((cross_entropy_held<LabelT, 8>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    else if (cols <= 1024 * 16) hipLaunchKernelGGL((cross_entropy_held<LabelT, 16>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    else                        hipLaunchKernelGGL((cross_entropy_held<LabelT, 32>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+}
+
 // ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
 template <typename IdT>
 __global__ void __launch_bounds__(256) gather_rows(const float* __restrict__ table, const IdT* __restrict__ ids, float* __restrict__ out,
@@ -331,29 +400,37 @@ __global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict_
 
 using namespace lg;
 
-extern "C" int lg_softmax_f32(const float* x, float* y, int64_t rows, int64_t cols) {
+extern "C" int lg_softmax_scaled_f32(const float* x, float* y, int64_t rows, int64_t cols, float scale) {
     LG_REQUIRE_INIT();
     LG_ARG(rows >= 0 && cols >= 1, "lg_softmax_f32: bad shape (%lld, %lld)", (long long)rows, (long long)cols);
     if (rows == 0) return LG_OK;
     LG_ARG(x && y, "lg_softmax_f32: NULL pointer");
     const unsigned blocks = unsigned((rows + 3) / 4);
     hipStream_t s = rt().stream;
-    if (cols <= 128)       hipLaunchKernelGGL(softmax_fwd<2>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
-    else if (cols <= 512)  hipLaunchKernelGGL(softmax_fwd<8>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
-    else if (cols <= 2048) hipLaunchKernelGGL(softmax_fwd<kRowRegs>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
-    else                   hipLaunchKernelGGL(softmax_fwd<0>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols);
+    if (cols <= 128)       hipLaunchKernelGGL(softmax_fwd<2>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols, scale);
+    else if (cols <= 512)  hipLaunchKernelGGL(softmax_fwd<8>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols, scale);
+    else if (cols <= 2048) hipLaunchKernelGGL(softmax_fwd<kRowRegs>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols, scale);
+    else                   hipLaunchKernelGGL(softmax_fwd<0>, dim3(blocks), dim3(256), 0, s, x, y, rows, cols, scale);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_softmax_f32(const float* x, float* y, int64_t rows, int64_t cols) {
+    return lg_softmax_scaled_f32(x, y, rows, cols, 1.0f);          // x * 1.0f is x, bit for bit
+}
+
+extern "C" int lg_softmax_scaled_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols, float scale) {
+    LG_REQUIRE_INIT();
+    LG_ARG(rows >= 0 && cols >= 1, "lg_softmax_bwd_f32: bad shape");
+    if (rows == 0) return LG_OK;
+    LG_ARG(y && g && dx, "lg_softmax_bwd_f32: NULL pointer");
+    hipLaunchKernelGGL(softmax_bwd, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, rt().stream, y, g, dx, rows, cols, scale);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
 
 extern "C" int lg_softmax_bwd_f32(const float* y, const float* g, float* dx, int64_t rows, int64_t cols) {
-    LG_REQUIRE_INIT();
-    LG_ARG(rows >= 0 && cols >= 1, "lg_softmax_bwd_f32: bad shape");
-    if (rows == 0) return LG_OK;
-    LG_ARG(y && g && dx, "lg_softmax_bwd_f32: NULL pointer");
-    hipLaunchKernelGGL(softmax_bwd, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, rt().stream, y, g, dx, rows, cols);
-    LG_CHECK_LAUNCH();
-    return LG_OK;
+    return lg_softmax_scaled_bwd_f32(y, g, dx, rows, cols, 1.0f);
 }
 
 extern "C" int lg_layernorm_f32(const float* x, const float* w, const float* b, float* y, float* xhat, float* rstd,
@@ -422,7 +499,16 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     const dim3 grid(unsigned((rows + 3) / 4)), block(256);
     const float inv_rows = float(1.0 / double(rows));
     hipStream_t s = rt().stream;
-    if (cols >= 4096 && rows < (int64_t(1) << 31)) {       // a vocabulary per row: one workgroup per row
+    static const char* ce_env = getenv("LG_CE_HELD");        // experiments only: 0 = the two-pass kernel for every width
+    if (cols >= 4096 && cols <= 1024 * 32 && rows < (int64_t(1) << 31) && !(ce_env && atoi(ce_env) == 0)) {
+        // a vocabulary per row that fits one workgroup's registers: a single pass over memory
+        if (label_itemsize == 2)      launch_cross_entropy_held(logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        else if (label_itemsize == 4) launch_cross_entropy_held(logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        else                          launch_cross_entropy_held(logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        LG_CHECK_LAUNCH();
+        return LG_OK;
+    }
+    if (cols >= 4096 && rows < (int64_t(1) << 31)) {       // wider still: one workgroup per row, two passes
         const dim3 wgrid{unsigned(rows)};
         if (label_itemsize == 2)
             hipLaunchKernelGGL(cross_entropy_wide<int16_t>, wgrid, block, 0, s, logits, static_cast<const int16_t*>(labels), dlogits, nll, cols, inv_rows, rt().status_dev);

@@ -335,3 +335,125 @@ def test_multi_tensor_adam_beyond_64_parameters(hip):
     for a, b in zip(*results):
         np.testing.assert_array_equal(a, b)
     assert np.abs(results[0][0] - p0).max() > 1e-3
+
+
+def test_bias_free_linear_waits_for_its_bias_row(hip):
+    """a large bias-free Linear stays unevaluated; `+ bias` right after it is one GEMM with the bias epilogue (BERT's decoder,
+    reference bert.py:227).  Values and all three gradients against the CPU backend's two-node form; the product used a second
+    time; the weight changed in place between the product and its first use (the product is a snapshot, cpu semantics)"""
+    from lightgrad_amd import nn
+    rng = np.random.RandomState(21)
+    rows, d_in, d_out = 1024, 128, 1100                      # 1.1 M elements: above the threshold
+    x, w, b = (rng.uniform(-1, 1, s).astype(np.float32) for s in [(rows, d_in), (d_out, d_in), (d_out,)])
+    g = rng.uniform(-1, 1, (rows, d_out)).astype(np.float32)
+
+    def run(T, second_use, poke):
+        lin = nn.Linear(d_in, d_out, bias=False)
+        lin.weight = T.from_numpy(w.copy())
+        tx, tb = T.from_numpy(x), T.from_numpy(b)
+        prod = lin(tx)
+        if T is not CpuTensor:
+            assert prod.is_lazy()
+        if poke:
+            wt = lin.weight
+            with light.no_grad():
+                wt *= 0.5                                     # in place; must not show in `prod`
+        y = prod + tb
+        if T is not CpuTensor:
+            assert prod.is_lazy() != poke                     # evaluated only by the in-place writer
+        if second_use:
+            y = y + prod * 0.25
+        (y * T.from_numpy(g, requires_grad=False)).backward(allow_fill=True)
+        return y.numpy(), tx.grad.numpy(), lin.weight.grad.numpy(), tb.grad.numpy()
+
+    for second_use, poke in [(False, False), (True, False), (False, True)]:
+        want, got = run(CpuTensor, second_use, poke), run(hip, second_use, poke)
+        for name, a, e in zip(["y", "dx", "dW", "db"], got, want):
+            scale = np.abs(e).max()
+            np.testing.assert_allclose(a, e, rtol=1e-5, atol=2e-6 * scale, err_msg="%s second_use=%s poke=%s" % (name, second_use, poke))
+    # a small product is evaluated at once; so is one under no_grad that is read directly
+    small = hip.from_numpy(x[:8]).linear(hip.from_numpy(w))
+    assert not small.is_lazy()
+    with light.no_grad():
+        big = hip.from_numpy(x).linear(hip.from_numpy(w))
+        np.testing.assert_allclose(big.numpy(), x @ w.T, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose((hip.from_numpy(x).linear(hip.from_numpy(w)) + hip.from_numpy(b)).numpy(), x @ w.T + b, rtol=1e-5, atol=1e-5)
+
+
+def test_cross_entropy_row_held_in_registers_widths(hip):
+    """widths on both sides of every register-count variant of the one-pass kernel (8 / 16 / 32 values per thread) and past
+    its limit (two-pass kernel), bad labels included"""
+    rng = np.random.RandomState(8)
+    for c in [4096, 8192, 8193, 12000, 16384, 16385, 32768, 32769]:
+        n = 5
+        logits = rng.uniform(-6, 6, (n, c)).astype(np.float32)
+        logits[1, c - 7:] = -np.inf
+        labels = rng.randint(0, c - 8, n).astype(np.int32)
+        labels[3] = -1 - labels[3]                                  # numpy-style negative label
+        want_loss, want_grad = O.cross_entropy(logits, labels.astype(np.int64))
+        y = hip.from_numpy(logits)
+        loss = light.loss.cross_entropy(y, hip.from_numpy(labels, requires_grad=False))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), want_loss, rtol=2e-5, err_msg=str(c))
+        np.testing.assert_allclose(y.grad.numpy(), want_grad, rtol=2e-5, atol=1e-9, err_msg=str(c))
+
+
+def test_attention_products_take_the_layout_of_their_consumers(hip):
+    """head-split attention (reference examples/bert.py:68-88): `probs @ v` lands in (b, s, h, d) memory order, so the head
+    merge `transpose(0, 2, 1, 3).reshape(b, s, h*d)` is a view; the gradients of the head-split views q, k^T, v come out in
+    the layout of those views, so their way back through transpose / reshape is a view as well.  Values against the CPU tape."""
+    rng = np.random.RandomState(31)
+    b, s, h, d = 3, 16, 2, 8
+    xs = [rng.uniform(-1, 1, (b, s, h * d)).astype(np.float32) for _ in range(3)]
+    gn = rng.uniform(-1, 1, (b, s, h * d)).astype(np.float32)
+
+    def run(T):
+        tq, tk, tv = (T.from_numpy(x) for x in xs)
+        q = tq.reshape(b, s, h, d).transpose(0, 2, 1, 3)
+        k = tk.reshape(b, s, h, d).transpose(0, 2, 3, 1)
+        v = tv.reshape(b, s, h, d).transpose(0, 2, 1, 3)
+        probs = (q @ k * 0.5).softmax(axis=-1)
+        ctx_heads = probs @ v
+        merged = ctx_heads.transpose(0, 2, 1, 3)
+        if T is not CpuTensor:
+            assert merged.is_contiguous() and not ctx_heads.is_contiguous()
+        out = merged.reshape(b, s, h * d)
+        (out * T.from_numpy(gn, requires_grad=False)).backward(allow_fill=True)
+        if T is not CpuTensor:
+            for leaf in (tq, tk, tv):
+                assert leaf.grad.is_contiguous()
+        return [out.numpy()] + [t.grad.numpy() for t in (tq, tk, tv)]
+
+    for name, got, want in zip(["context", "dq", "dk", "dv"], run(hip), run(CpuTensor)):
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=name)
+    # the general form: any dense permutation with a unit stride among the last two dims, against numpy
+    from lightgrad_amd.autograd.hip import ops as H
+    a, c = rng.uniform(-1, 1, (2, 3, 5, 7)).astype(np.float32), rng.uniform(-1, 1, (2, 3, 7, 4)).astype(np.float32)
+    want = a @ c
+    for perm in [(0, 1, 2, 3), (0, 2, 1, 3), (1, 0, 2, 3), (2, 0, 1, 3), (0, 1, 3, 2), (0, 3, 1, 2), (3, 1, 0, 2)]:
+        # memory order `perm` (outermost first) of the (2, 3, 5, 4) result
+        shape = want.shape
+        strides, run_ = [0] * 4, 1
+        for dim in reversed(perm):
+            strides[dim] = run_
+            run_ *= shape[dim]
+        if 1 not in (strides[-1], strides[-2]):
+            continue
+        out = H._gemm(hip.from_numpy(a), hip.from_numpy(c), out_strides=tuple(strides))
+        assert out.strides == tuple(strides) or out.is_contiguous()
+        np.testing.assert_allclose(out.numpy(), want, rtol=1e-5, atol=1e-6, err_msg=str(perm))
+
+
+def test_scaled_softmax_is_the_two_kernel_form_bit_for_bit(hip):
+    rng = np.random.RandomState(32)
+    for shape, scale in [((4, 2, 16, 16), 8.0 ** -1), ((5, 300), 0.3), ((3, 2500), 1.7)]:
+        xn, gn = rng.uniform(-4, 4, shape).astype(np.float32), rng.uniform(-1, 1, shape).astype(np.float32)
+        x1, x2 = hip.from_numpy(xn), hip.from_numpy(xn)
+        y1 = x1.scaled_softmax(scale)
+        y2 = (x2 * scale).softmax(axis=-1)
+        (y1 * hip.from_numpy(gn, requires_grad=False)).backward(allow_fill=True)
+        (y2 * hip.from_numpy(gn, requires_grad=False)).backward(allow_fill=True)
+        np.testing.assert_array_equal(y1.numpy(), y2.numpy())
+        np.testing.assert_array_equal(x1.grad.numpy(), x2.grad.numpy())
+        want = O.softmax_forward(xn * np.float32(scale), axis=-1)
+        np.testing.assert_allclose(y1.numpy(), want, rtol=1e-5, atol=1e-7)

@@ -51,4 +51,18 @@ for name, fn in cases.items():
     us = timed(fn)
     total += us
     print("%-44s %7.2f us" % (name, us))
+out2 = HipTensor.empty((1024 * 1024,), requires_grad=False)
+
+
+def pair():
+    # what linear.backward issues when no gradient hook is waiting on dW: both products in ONE launch (lg_gemm_pair_*)
+    L.check(lib.lg_gemm_pair_begin())
+    L.check(lib.lg_gemm_f32(1, 0, 512, 784, 1024, g1.ptr, 512, 0, x.ptr, 784, 0, out.ptr, 784, 0, 1, 0))
+    L.check(lib.lg_gemm_f32(0, 0, 1024, 784, 512, g1.ptr, 512, 0, w1.ptr, 784, 0, out2.ptr, 784, 0, 1, 0))
+    L.check(lib.lg_gemm_pair_end())
+
+
+us_pair = timed(pair)
+print("%-44s %7.2f us" % ("dW1 and dx as one launch (lg_gemm_pair_*)", us_pair))
+print("the six products with dW1 and dx paired: %.1f us" % (total - timed(cases["dx    g1 @ W1    (1024x784, K=512) NN"]) - timed(cases["dW1   g1^T @ x   (512x784, K=1024) TN"]) + us_pair))
 print("knobs: LG_GEMM_TILE=%s LG_GEMM_SLICES=%s   total %.1f us" % (os.environ.get("LG_GEMM_TILE", "auto"), os.environ.get("LG_GEMM_SLICES", "auto"), total))

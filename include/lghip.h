@@ -66,6 +66,19 @@ int lg_device_info(lg_device_info_t* out);
 void* lg_stream(void);                          /* hipStream_t of the library (for liblghip_comm / profilers) */
 int lg_sync(void);                              /* block until the stream is idle */
 
+/* ---- side stream: work off the critical path ------------------------------------
+ * New design (no reference analog: the reference's OpenCL backend has one in-order queue, opencl/device.py:68-115).
+ * Launches (and the allocations they make) between lg_side_begin and lg_side_end go to a second, lower-priority HIP stream
+ * that first waits for everything enqueued on the main stream so far; the main stream does NOT wait for them until
+ * lg_side_join (also implied by lg_sync, lg_memcpy_d2h, lg_graph_launch, lg_graph_end, lg_pool_trim).  Meant for parameter
+ * gradients: backward continues along the activation gradients while dW / db / LayerNorm and embedding gradients are
+ * computed next to it.  Inside a captured graph the brackets become parallel branches.  The caller must not let the main
+ * stream touch what a side launch writes before the join; blocks handed to lg_free while side work is pending are parked
+ * until the join, so buffers a side launch READS may be released at any time.  Brackets do not nest. */
+int lg_side_begin(void);
+int lg_side_end(void);
+int lg_side_join(void);
+
 /* caching, stream-ordered allocator (replaces device.mem_pool.allocate, opencl/tensor.py:64).
  * lg_free returns the block to the pool immediately: safe because all users are on one stream. */
 int lg_malloc(void** ptr, size_t bytes);
@@ -312,6 +325,20 @@ int lg_scatter_add_axis_f32(float* dst, int64_t outer, int64_t axis_len, int64_t
  * products must not read each other's outputs. */
 int lg_gemm_pair_begin(void);
 int lg_gemm_pair_end(void);
+
+/* Many weight-gradient products in ONE launch.  Between lg_gemm_group_begin and lg_gemm_group_end, lg_gemm_f32 /
+ * lg_gemm_rowsum_f32 calls of the form dW (+ db) = g^T @ x (transA = 1, transB = 0, one matrix, at most 1024 output tiles of
+ * 64 x 64) are prepared and QUEUED instead of launched (up to 14), and so are lg_layernorm_param_grads_f32 calls (up to 8);
+ * anything else inside the bracket runs as usual.  The queue outlives the bracket: lg_gemm_group_flush launches it - one
+ * GEMM kernel, one LayerNorm kernel.  It is also launched when full, when a call writes where a queued one writes, and
+ * before lg_sync, lg_memcpy_d2h, lg_graph_launch and the end of a capture.  Results are those of the immediate launches;
+ * only WHEN they are computed changes: the caller must keep the queued calls' operands alive and unchanged and must not read
+ * their outputs until the flush.  Made for the backward pass of a deep network: each Linear's weight gradient is a small
+ * product with a long K (12 us alone, most of it launch, prologue and split-K hand-off on a handful of workgroups) that
+ * nothing but the optimizer waits for; together they cost what the largest costs.  New design, no reference analog. */
+int lg_gemm_group_begin(void);
+int lg_gemm_group_flush(void);
+int lg_gemm_group_end(void);
 
 /* ---- the skinny output layer and its loss (csrc/head.hip) ------------------------
  * An nn.Linear with at most 16 output features (a classifier head; reference nn.py:90-96) followed by

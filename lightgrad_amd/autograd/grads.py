@@ -84,17 +84,25 @@ class Gradients(object):
     def backward(ctx, grad):
         """Propagate `grad` (gradient of the tensor produced by `ctx`) to all ancestors."""
         out_grads = {id(ctx): grad}
-        for node in Gradients._schedule(ctx):
-            out_grad = out_grads.pop(id(node), None)
-            if out_grad is None:
-                # reachable only through tensors that do not require gradients
-                continue
-            Gradients.disable()
-            try:
-                node._backpropagate(out_grad)
-            finally:
-                Gradients.enable()
-            # the accumulated .grad of each parent is the out-grad of the node that made it
-            for t in node.parent_tensors:
-                if t.ctx is not None and t.grad is not None:
-                    out_grads[id(t.ctx)] = t.grad
+        order = Gradients._schedule(ctx)
+        # a backend may bracket the whole pass (HipTensor: parameter-gradient kernels on a second stream, joined at the end)
+        begin = getattr(grad, "_backward_pass_begins", None)
+        finish = begin(len(order)) if begin is not None else None
+        try:
+            for node in order:
+                out_grad = out_grads.pop(id(node), None)
+                if out_grad is None:
+                    # reachable only through tensors that do not require gradients
+                    continue
+                Gradients.disable()
+                try:
+                    node._backpropagate(out_grad)
+                finally:
+                    Gradients.enable()
+                # the accumulated .grad of each parent is the out-grad of the node that made it
+                for t in node.parent_tensors:
+                    if t.ctx is not None and t.grad is not None:
+                        out_grads[id(t.ctx)] = t.grad
+        finally:
+            if finish is not None:
+                finish()

@@ -41,6 +41,9 @@ PROTOTYPES = {
     "lg_device_info": (c_int, [POINTER(DeviceInfo)]),
     "lg_stream": (c_void_p, []),
     "lg_sync": (c_int, []),
+    "lg_side_begin": (c_int, []),
+    "lg_side_end": (c_int, []),
+    "lg_side_join": (c_int, []),
     "lg_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "lg_free": (c_int, [c_void_p]),
     "lg_pool_trim": (c_int, []),
@@ -71,6 +74,9 @@ PROTOTYPES = {
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lg_gemm_pair_begin": (c_int, []),
     "lg_gemm_pair_end": (c_int, []),
+    "lg_gemm_group_begin": (c_int, []),
+    "lg_gemm_group_flush": (c_int, []),
+    "lg_gemm_group_end": (c_int, []),
     "lg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,
                                  c_double, c_double, c_double, c_double, c_int]),
     "lg_adam_step_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,

@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 from ..func import Function
 import weakref
-from .tensor import HipTensor, HipBuffer, contiguous_strides, flush_lazy_readers
+from .tensor import HipTensor, HipBuffer, GradGroup, SideStream, contiguous_strides, flush_lazy_readers
 from . import lib as _l
 from .lib import i64
 
@@ -880,7 +880,11 @@ class getitem(Function):
             if acc is not None and acc.is_contiguous() and acc._dtype == _F32:
                 if table._consume_zero_pending():
                     acc.fill(0)
-                _scatter_add_rows(shape, idx, out_grad, into=acc)
+                if SideStream.usable_for(table):
+                    with SideStream.bracket(reads=(idx, out_grad), writes=(acc,)):
+                        _scatter_add_rows(shape, idx, out_grad, into=acc)
+                else:
+                    _scatter_add_rows(shape, idx, out_grad, into=acc)
                 table._notify_grad_written()
                 return None
             return _scatter_add_rows(shape, idx, out_grad)
@@ -1112,62 +1116,80 @@ class linear(Function):
         # leaf operands that already own a gradient buffer (parameters after zero_grad, a re-used input) get their
         # gradient ADDED in place by the producing kernel (GEMM with beta = 1 / reduction with accumulate) and None
         # is reported for them - tensor.py:118's `grad += g` without the temporary and the extra pass
-        dw = dx = db = None
         want_db = has_bias and bias.requires_grad
+        acc_w = weight._grad_accumulator() if weight.requires_grad else None
+        acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+        acc_b = bias._grad_accumulator() if want_db else None
+        acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+        rows = g2._shape[0]
+        in_place = rows > 0 and x.requires_grad and acc_w is not None and (not want_db or acc_b is not None)
+        if in_place and GradGroup.usable_for(weight, bias):
+            # deep tape: dW (+ db) are QUEUED inside the library and launched with all the other weight gradients when the
+            # pass ends; the main chain carries on with dx, the only result the rest of the backward pass waits for
+            with GradGroup.issue(reads=(g2, x2), writes=(acc_w, acc_b)):
+                linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
+            return linear._input_product(x, weight, g2) + ((None,) if not has_bias else (None, None))
+        if in_place and SideStream.usable_for(weight, bias):
+            # deep tape: dW (+ db) go in place into the parameters' gradient buffers from the SIDE stream while the main
+            # stream carries on with dx, the only result the rest of the backward pass waits for
+            with SideStream.bracket(reads=(g2, x2), writes=(acc_w, acc_b)):
+                linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
+            return linear._input_product(x, weight, g2) + ((None,) if not has_bias else (None, None))
         # dW (+ db) and dx are independent products: when both are wanted they go out as ONE launch (lg_gemm_pair_*) - unless a
         # data-parallel exchange hangs on the weight gradient's kernel being enqueued the moment it is reported written
-        paired = (weight.requires_grad and x.requires_grad and g2._shape[0] > 0 and weight._grad_written_hook is None
+        paired = (weight.requires_grad and x.requires_grad and rows > 0 and weight._grad_written_hook is None
                   and (bias is None or bias._grad_written_hook is None))
         if paired:
             _l.check(_l.lib().lg_gemm_pair_begin())
         try:
-            return linear._backward_products(x, x2, weight, bias, has_bias, want_db, g2)
+            dw, db = linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
+            dx, = linear._input_product(x, weight, g2)
         finally:
             if paired:
                 _l.check(_l.lib().lg_gemm_pair_end())
+        return (dx, dw, db) if has_bias else (dx, dw)
 
     @staticmethod
-    def _backward_products(x, x2, weight, bias, has_bias, want_db, g2):
-        dw = dx = db = None
-        if weight.requires_grad and want_db and g2._shape[0] > 0 and _rowsum_column_is_cheap(weight._shape[0], weight._shape[1]):
+    def _weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b):
+        """(dW, db) = (g^T @ x, column sums of g): each added into its accumulator when there is one (None is returned for
+        it then and the parameter's hook is told), else returned as a fresh tensor; None for a gradient nobody wants"""
+        dw = db = None
+        rows = g2._shape[0]
+        if weight.requires_grad and want_db and rows > 0 and _rowsum_column_is_cheap(weight._shape[0], weight._shape[1]):
             # dW and db from one launch: db = column sums of g = row sums of g^T, a virtual extra column of the product
-            acc_w, acc_b = weight._grad_accumulator(), bias._grad_accumulator()
-            acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
-            acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
             out_w, out_b = _gemm_rowsum(_swap_last(g2), x2, accumulate_into=acc_w,
                                         overwrite=acc_w is not None and weight._consume_zero_pending(),
                                         rowsum_into=acc_b, rowsum_overwrite=acc_b is not None and bias._consume_zero_pending())
             dw = out_w if acc_w is None else None
             db = out_b if acc_b is None else None
-            if acc_w is not None:
-                weight._notify_grad_written()
-            if acc_b is not None:
-                bias._notify_grad_written()
             want_db = False
         elif weight.requires_grad:
-            acc = weight._grad_accumulator()
-            if acc is not None and acc.is_contiguous():
-                _gemm(_swap_last(g2), x2, accumulate_into=acc, overwrite=weight._consume_zero_pending())
-                weight._notify_grad_written()
+            if acc_w is not None:
+                _gemm(_swap_last(g2), x2, accumulate_into=acc_w, overwrite=weight._consume_zero_pending())
             else:
                 dw = _gemm(_swap_last(g2), x2)
-        if x.requires_grad:
-            acc = x._grad_accumulator()
-            if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
-                _gemm(g2, weight, accumulate_into=acc, overwrite=x._consume_zero_pending())
-                (x._view_of_leaf if (x._view_of_leaf is not None and x._grad is None) else x)._notify_grad_written()
-            else:
-                dx = _gemm(g2, weight).reshape(*x._shape)
-        if not has_bias:
-            return dx, dw
         if want_db:
-            acc = bias._grad_accumulator()
-            if acc is not None and acc.is_contiguous():
-                _reduce_into(acc, g2, (0,), overwrite=bias._consume_zero_pending())
-                bias._notify_grad_written()
+            if acc_b is not None:
+                _reduce_into(acc_b, g2, (0,), overwrite=bias._consume_zero_pending())
             else:
                 db = _reduce(_l.RED_SUM, g2, (0,), False)
-        return dx, dw, db
+        if weight.requires_grad and acc_w is not None:
+            weight._notify_grad_written()
+        if bias is not None and bias.requires_grad and acc_b is not None:
+            bias._notify_grad_written()
+        return dw, db
+
+    @staticmethod
+    def _input_product(x, weight, g2):
+        """(dx,) = (g @ W,), or (None,) after adding it into x's own gradient buffer / when x wants none"""
+        if not x.requires_grad:
+            return (None,)
+        acc = x._grad_accumulator()
+        if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
+            _gemm(g2, weight, accumulate_into=acc, overwrite=x._consume_zero_pending())
+            (x._view_of_leaf if (x._view_of_leaf is not None and x._grad is None) else x)._notify_grad_written()
+            return (None,)
+        return (_gemm(g2, weight).reshape(*x._shape),)
 
 
 def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
@@ -1407,15 +1429,25 @@ class layer_norm(Function):
         acc_b = bias._grad_accumulator() if bias.requires_grad else None
         acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
         acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
-        for t in (acc_w, acc_b):
-            if t is not None:
-                flush_lazy_readers(t)
         dw = acc_w if acc_w is not None else HipTensor.empty((cols,))
         db = acc_b if acc_b is not None else HipTensor.empty((cols,))
-        _l.check(_l.lib().lg_layernorm_param_grads_f32(
-            g.ptr, xhat.ptr, dw.ptr, db.ptr, rows, cols,
-            1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
-            1 if (acc_b is not None and not bias._consume_zero_pending()) else 0))
+
+        def param_grads():
+            for t in (acc_w, acc_b):
+                if t is not None:
+                    flush_lazy_readers(t)
+            _l.check(_l.lib().lg_layernorm_param_grads_f32(
+                g.ptr, xhat.ptr, dw.ptr, db.ptr, rows, cols,
+                1 if (acc_w is not None and not weight._consume_zero_pending()) else 0,
+                1 if (acc_b is not None and not bias._consume_zero_pending()) else 0))
+        if acc_w is not None and acc_b is not None and GradGroup.usable_for(weight, bias):
+            with GradGroup.issue(reads=(g, xhat), writes=(acc_w, acc_b)):          # queued, like a Linear's dW
+                param_grads()
+        elif acc_w is not None and acc_b is not None and SideStream.usable_for(weight, bias):
+            with SideStream.bracket(reads=(g, xhat), writes=(acc_w, acc_b)):      # off the critical path on a second stream
+                param_grads()
+        else:
+            param_grads()
         if acc_w is not None:
             weight._notify_grad_written()
         if acc_b is not None:

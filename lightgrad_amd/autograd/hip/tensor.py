@@ -54,12 +54,181 @@ class HipBuffer(object):
             _l._lib.lg_free(ptr)
 
 
+class GradGroup(object):
+    """Parameter-gradient kernels of a deep backward pass, queued and launched TOGETHER (lg_gemm_group_* in include/lghip.h).
+
+    In a transformer-sized tape (>= MIN_NODES nodes) the weight gradient of every Linear is a small product with a long K -
+    12 us alone, most of it launch, prologue and split-K hand-off on a handful of workgroups - and nothing but the optimizer
+    waits for it; the same goes for LayerNorm's weight / bias gradients (7.5 us each).  While the pass runs, those launches
+    are queued inside the library (`with GradGroup.issue(reads, writes)`) and go out as one GEMM launch + one LayerNorm launch
+    when the pass ends (tiny-BERT: 13 + 6 launches become 1 + 1).  Shallow tapes (the MLP) do not use it:
+    there dW and dx share a launch (lg_gemm_pair_*), which is the better deal when the optimizer follows at once.
+
+    Hazards: the queued launches read activations / gradients later - `keep` holds them alive, and an in-place writer into
+    their storage or into the gradient buffers (flush_lazy_readers is the hook of every in-place writer) flushes the queue
+    first; the library itself flushes before anything that exposes results to the host or to another graph."""
+    MIN_NODES = 48
+    enabled = os.environ.get("LIGHTGRAD_GRAD_GROUP", "1") != "0"
+    depth = 0             # nested backward passes (WrapperFunction replays its inner tape with Gradients.backward)
+    active = False
+    issuing = False
+    touched = set()       # id(HipBuffer) of operands and outputs of queued launches
+    keep = []
+
+    @staticmethod
+    def pass_begins(n_nodes):
+        G = GradGroup
+        if G.depth == 0:
+            G.active = G.enabled and n_nodes >= G.MIN_NODES
+        G.depth += 1
+
+    @staticmethod
+    def pass_ends():
+        G = GradGroup
+        G.depth -= 1
+        if G.depth == 0 and G.active:
+            G.active = False
+            G.flush()
+
+    @staticmethod
+    def flush():
+        G = GradGroup
+        del G.keep[:]
+        G.touched.clear()
+        _l.check(_l.lib().lg_gemm_group_flush())
+
+    @staticmethod
+    def usable_for(*params) -> bool:
+        """not when someone waits for the moment a gradient's kernel is enqueued (dist.DataParallel starts its exchange from
+        that hook)"""
+        G = GradGroup
+        if not G.active or G.issuing:
+            return False
+        for p in params:
+            if p is not None and p._grad_written_hook is not None:
+                return False
+        return True
+
+    class issue(object):
+        """`with GradGroup.issue(reads, writes): <launches the library may queue>`"""
+        __slots__ = ()
+
+        def __init__(self, reads, writes):
+            G = GradGroup
+            for t in reads:
+                if t is not None:
+                    G.touched.add(id(t.data))           # (.data: a lazy operand becomes real now, not at the flush)
+                    G.keep.append(t)
+            for t in writes:
+                if t is not None:
+                    _make_lazy_readers_real(t)          # snapshots of the old contents
+                    G.touched.add(id(t._data))
+
+        def __enter__(self):
+            GradGroup.issuing = True
+            _l.check(_l.lib().lg_gemm_group_begin())
+
+        def __exit__(self, *exc):
+            GradGroup.issuing = False
+            _l.check(_l.lib().lg_gemm_group_end())
+
+
+class SideStream(object):
+    """Parameter-gradient kernels on a second HIP stream (lg_side_* in include/lghip.h).
+
+    During a backward pass over a DEEP tape (a transformer: >= MIN_NODES tape nodes) the kernels that write parameter
+    gradients in place - dW / db of every Linear, LayerNorm's weight and bias gradients, embedding scatter-adds - do not sit
+    on the critical path: only the activation gradients feed the next node.  They are enqueued inside `with SideStream.bracket(...)`
+    and run next to the main chain (as parallel branches when the pass is captured into a hipGraph); the pass ends with a
+    join.  Shallow tapes (the MLP) keep everything on one stream - there the optimizer waits for every gradient at once and
+    one launch for dW and dx together is the better deal (lg_gemm_pair_*).
+
+    Hazards and how they are covered:
+      * a side kernel READS tensors made on the main stream: the bracket forks after everything enqueued so far, and lazy
+        operands are made real before the fork;
+      * it WRITES into gradient buffers: `written` remembers their storage until the join; an in-place writer on the main
+        stream (flush_lazy_readers is its hook) joins first;
+      * memory freed meanwhile is parked inside the library until the join."""
+    MIN_NODES = 48
+    # OFF unless asked for: measured on tiny-BERT (profiles/README.md r2) a hipGraph with these parallel branches replays in
+    # 3.8 ms instead of 0.86 ms - every edge between branches costs ~40 us in ROCm 7.2's graph executor - and the eager
+    # tape is host-bound either way.  GradGroup (above) gets the same work off the critical path inside ONE stream.
+    enabled = os.environ.get("LIGHTGRAD_SIDE_STREAM", "0") == "1"
+    depth = 0             # nested backward passes (WrapperFunction replays its inner tape with Gradients.backward)
+    active = False        # the running pass uses the side stream
+    in_bracket = False
+    written = set()       # id(HipBuffer) of storage with un-joined side writes
+
+    @staticmethod
+    def pass_begins(n_nodes):
+        S = SideStream
+        if S.depth == 0:
+            S.active = S.enabled and n_nodes >= S.MIN_NODES and not GradGroup.active
+        S.depth += 1
+        return S.pass_ends
+
+    @staticmethod
+    def pass_ends():
+        S = SideStream
+        S.depth -= 1
+        if S.depth == 0:
+            S.active = False
+            S.join()
+
+    @staticmethod
+    def join():
+        S = SideStream
+        if S.written:
+            S.written.clear()
+            _l.check(_l.lib().lg_side_join())
+
+    @staticmethod
+    def usable_for(*params) -> bool:
+        """may the gradients of these leaf parameters be written from the side stream?  Not when someone waits for the
+        moment they are enqueued (dist.DataParallel starts its exchange from that hook, on its own stream)"""
+        S = SideStream
+        if not S.active or S.in_bracket:
+            return False
+        for p in params:
+            if p is not None and p._grad_written_hook is not None:
+                return False
+        return True
+
+    class bracket(object):
+        __slots__ = ()
+
+        def __init__(self, reads, writes):
+            for t in reads:
+                if t is not None:
+                    t.data                      # lazy operands become real on the main stream, before the fork
+            for t in writes:
+                if t is not None:
+                    _make_lazy_readers_real(t)  # snapshots of the old contents, also before the fork
+                    SideStream.written.add(id(t._data))
+
+        def __enter__(self):
+            _l.check(_l.lib().lg_side_begin())
+            SideStream.in_bracket = True
+
+        def __exit__(self, *exc):
+            SideStream.in_bracket = False
+            _l.check(_l.lib().lg_side_end())
+
+
 def flush_lazy_readers(t) -> None:
     """call before any kernel WRITES into storage that already exists (in-place operators, fill, setitem, uploads,
     accumulating epilogues, optimizer updates, collectives): lazy tensors that were defined from the block's current
     contents (`relu` of a dense tensor, see HipTensor._lazy_source) are computed first, so that - like the reference,
     which evaluates relu at once (cpu/ops.py:226) - a later in-place change of the source never shows in them.
     Costs one attribute test when nobody is waiting (the normal case)."""
+    if SideStream.written and not SideStream.in_bracket and id(t._data) in SideStream.written:
+        SideStream.join()              # a main-stream writer into storage the side stream is still writing
+    if GradGroup.touched and not GradGroup.issuing and id(t._data) in GradGroup.touched:
+        GradGroup.flush()              # ... or that a queued launch will read or write
+    _make_lazy_readers_real(t)
+
+
+def _make_lazy_readers_real(t) -> None:
     buf = t._data
     if buf is not None and buf.lazy_readers:
         waiting, buf.lazy_readers = buf.lazy_readers, None
@@ -128,6 +297,16 @@ class HipDevice(object):
 class HipTensor(AbstractTensor):
 
     _adopt_first_grad = True      # intermediates share their first gradient (see AbstractTensor)
+
+    @staticmethod
+    def _backward_pass_begins(n_nodes):
+        GradGroup.pass_begins(n_nodes)
+        side_ends = SideStream.pass_begins(n_nodes)
+
+        def ends():
+            GradGroup.pass_ends()
+            side_ends()
+        return ends
 
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):

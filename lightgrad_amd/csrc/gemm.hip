@@ -165,6 +165,34 @@ __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, Ge
 #undef LG_TILE_OWNS_LDS
 }
 
+// Up to kGroupMax independent products of ONE layout in one launch: the weight gradients dW (+ db) = g^T @ x of the Linear
+// layers of a deep network (M-contiguous A, N-contiguous B).  Each of them is a small output with a long K - 12 us alone, 7 of
+// them launch, prologue, split-K hand-off and epilogue, with a handful of workgroups on a 256-CU chip; queued during the
+// backward pass and launched together at its end they cost what the largest one costs.
+constexpr int kGroupMax = 14;
+struct GemmGroup {
+    GemmArgs p[kGroupMax];
+    int      first[kGroupMax + 1];      // first workgroup of each product; first[count] = all workgroups
+    int      count;
+};
+
+static_assert(sizeof(GemmGroup) <= 4096, "the group travels as kernel arguments");
+
+template <int PD>
+__global__ void __launch_bounds__(256) sgemm_group_wgrad(GemmGroup grp) {
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 32, false, false, 1>()];
+    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
+    constexpr bool VA = true, VB = true, AKC = false, BKC = false;
+    int which = 0;
+    while (which + 1 < grp.count && int(blockIdx.x) >= grp.first[which + 1]) ++which;      // uniform: scalar loads
+    const GemmArgs& g = grp.p[which];
+#define LG_TILE_OWNS_LDS 0
+#define LG_TILE_BID (int(blockIdx.x) - grp.first[which])
+#include "gemm_tile_body.inc"
+#undef LG_TILE_BID
+#undef LG_TILE_OWNS_LDS
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int KG>
 static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     dim3 grid(g.nwg), block(WM * WN * KG * 64);
@@ -231,6 +259,79 @@ static bool pair_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, in
     P.args[slot] = g;
     P.count = slot + 1;
     return true;
+}
+
+// ---- many weight-gradient products in one launch (lg_gemm_group_begin / _end / _flush) ----------------------------------
+// Between begin and end, a product that resolves to the 64x64 tile in the A^T-form layout (M-contiguous A, N-contiguous B,
+// one matrix, at most kGroupTiles output tiles) is prepared and QUEUED; the queue outlives the bracket and goes out as one
+// launch on lg_gemm_group_flush, when it is full, when a product arrives that writes where a queued one writes (a weight
+// shared by two layers), and before anything that lets the host or another graph see results (lg_sync, device-to-host
+// copies, graph launch, the end of a capture).  The CALLER keeps the operands alive and unchanged, and does not read the
+// results, until then.
+constexpr int kGroupTiles = 1024;
+struct GroupState {
+    int       active = 0;
+    int       count = 0;
+    int64_t   tiles = 0;          // tickets handed to the queued products
+    GemmGroup grp;
+};
+static GroupState& group_state() { static GroupState s; return s; }
+
+static int group_flush() {
+    GroupState& G = group_state();
+    if (G.count == 0) return LG_OK;
+    int rc = LG_OK;
+    if (G.count == 1) {
+        pair_launch_single(G.grp.p[0], 0);
+    } else {
+        // small products first: theirs are the long dependency chains (few workgroups, split-K hand-off and fold), a product
+        // with hundreds of tiles (BERT's decoder) fills the chip behind them
+        GemmArgs sorted[kGroupMax];
+        int n = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < G.count; ++i)
+                if ((G.grp.p[i].nwg > 256) == (pass == 1)) sorted[n++] = G.grp.p[i];
+        G.grp.first[0] = 0;
+        for (int i = 0; i < G.count; ++i) { G.grp.p[i] = sorted[i]; G.grp.first[i + 1] = G.grp.first[i] + sorted[i].nwg; }
+        G.grp.count = G.count;
+        hipLaunchKernelGGL((sgemm_group_wgrad<kSmallTilePrefetch>), dim3(G.grp.first[G.count]), dim3(256), 0, rt().stream, G.grp);
+    }
+    for (int i = 0; i < G.count; ++i)
+        if (G.grp.p[i].W) { const int r = lg_free(G.grp.p[i].W); if (r != LG_OK) rc = r; }     // stream-ordered
+    G.count = 0;
+    G.tiles = 0;
+    return rc;
+}
+
+// true: `g` (fully prepared, workspace allocated) has been queued
+static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, int64_t batch, int& rc) {
+    GroupState& G = group_state();
+    rc = LG_OK;
+    if (G.active != 1 || pair_state().active) return false;
+    const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n;
+    if (akc || bkc || !va || !vb || batch != 1 || tiles > kGroupTiles || g.relu_a || g.relu_b) return false;
+    bool clash = false;
+    for (int i = 0; i < G.count; ++i)
+        clash = clash || G.grp.p[i].C == g.C || (g.rowsum && G.grp.p[i].rowsum == g.rowsum);
+    if (clash || G.count == kGroupMax || G.tiles + tiles > rt().n_gemm_tickets / 2) {     // (the upper half: LayerNorm's queue)
+        rc = group_flush();
+        if (rc != LG_OK) return false;
+    }
+    g.tickets = rt().gemm_tickets + G.tiles;            // disjoint tickets: the products fold their K-slices side by side
+    G.tiles += tiles;
+    G.grp.p[G.count] = g;
+    if (G.count == 0) G.grp.first[0] = 0;
+    G.grp.first[G.count + 1] = G.grp.first[G.count] + g.nwg;
+    G.count += 1;
+    return true;
+}
+
+bool gemm_group_is_open() { return group_state().active == 1; }
+
+int gemm_group_flush_pending() {
+    const int rc = group_flush();
+    const int rc2 = ln_group_flush_pending();
+    return rc != LG_OK ? rc : rc2;
 }
 
 #ifdef LG_GEMM_TIMELINE
@@ -319,6 +420,9 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     // by the workgroup barrier, which more waves of the SAME workgroup do not hide: 25.9 -> 25.4 us at 1024x512x1024)
     if constexpr (BM == 64 && BN == 64 && WM == 2 && WN == 2 && KG == 1) {
         if (pair_try_defer(g, akc, bkc, va, vb, batch)) return LG_OK;
+        int grc = LG_OK;
+        if (group_try_defer(g, akc, bkc, va, vb, batch, grc)) return LG_OK;
+        if (grc != LG_OK) return grc;
     }
     if (pair_state().count) {                         // something else inside a pair bracket: what is pending goes first
         const int prc = pair_flush(false);
@@ -435,7 +539,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
             // transformer layer's Linear backward that is worth more than the K-group tile (tiny-BERT, 12 Linear layers:
             // 0.980 -> 0.901 ms per forward+backward).  LG_GEMM_PAIR_KG=1 (experiments) lets the K-group tile win again.
             static const char* pair_kg_env = getenv("LG_GEMM_PAIR_KG");
-            const bool keep_for_pair = lg::pair_state().active == 1 && !(pair_kg_env && atoi(pair_kg_env) == 1);
+            const bool keep_for_pair = (lg::pair_state().active == 1 && !(pair_kg_env && atoi(pair_kg_env) == 1))
+                                       || (lg::group_state().active == 1 && !akc && !bkc && nblocks(64, 64) <= lg::kGroupTiles);
             if (tile == 9 && batch == 1 && !keep_for_pair) {
                 // Too few 64x64 tiles to fill the chip: split K across workgroups (slabs + ticket + fold) or INSIDE a workgroup
                 // on a half-size tile (64x32 / 32x64 with two K-groups, one LDS exchange)?  Same model as launch_config (us):
@@ -548,5 +653,29 @@ extern "C" int lg_gemm_pair_end(void) {
     P.active = 0;
     if (rc != LG_OK) return rc;
     LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_group_begin(void) {
+    LG_REQUIRE_INIT();
+    GroupState& G = lg::group_state();
+    LG_ARG(G.active == 0, "lg_gemm_group_begin: a group bracket is already open");
+    G.active = 1;                  // what earlier brackets queued stays queued
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_group_flush(void) {
+    LG_REQUIRE_INIT();
+    const int rc = lg::gemm_group_flush_pending();
+    if (rc != LG_OK) return rc;
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_group_end(void) {
+    LG_REQUIRE_INIT();
+    GroupState& G = lg::group_state();
+    LG_ARG(G.active != 0, "lg_gemm_group_end: no group bracket is open");
+    G.active = 0;                  // nothing is launched here: lg_gemm_group_flush does that
     return LG_OK;
 }

@@ -153,13 +153,29 @@ __global__ void __launch_bounds__(256) layernorm_bwd(const float* __restrict__ g
 // one thread per column (coalesced along the row), the rows split over blockIdx.y; with more than one split the
 // partial sums are published write-through, a per-column-block ticket elects the last workgroup, which folds them in
 // split order (cdna_hip_programming.md, in-launch split-K recipe).  Replaces mul + two column sums + two adds.
-__global__ void __launch_bounds__(256) layernorm_param_grads(const float* __restrict__ g, const float* __restrict__ xhat,
-                                                             float* dw, float* db, float* partial, int* tickets,
-                                                             int64_t rows, int64_t cols, int64_t chunk, int acc_w, int acc_b) {
-    const int64_t c_raw = int64_t(blockIdx.x) * 256 + threadIdx.x;
+struct LnParamGrads {
+    const float* g;
+    const float* xhat;
+    float*       dw;
+    float*       db;
+    float*       partial;      // [splits][2][cols] when splits > 1
+    int*         tickets;      // one per column block
+    int64_t      rows, cols, chunk;
+    int          blocks_x, splits;
+    int          acc_w, acc_b;
+};
+
+__device__ __forceinline__ void layernorm_param_grads_body(const LnParamGrads& a, int block_x, int64_t split) {
+    const float* __restrict__ g = a.g;
+    const float* __restrict__ xhat = a.xhat;
+    float* dw = a.dw;
+    float* db = a.db;
+    float* partial = a.partial;
+    const int64_t rows = a.rows, cols = a.cols, chunk = a.chunk, splits = a.splits;
+    const int acc_w = a.acc_w, acc_b = a.acc_b;
+    const int64_t c_raw = int64_t(block_x) * 256 + threadIdx.x;
     const bool live = c_raw < cols;
     const int64_t c = live ? c_raw : cols - 1;
-    const int64_t split = blockIdx.y, splits = gridDim.y;
     const int64_t r0 = split * chunk;
     const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
     float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -185,7 +201,7 @@ __global__ void __launch_bounds__(256) layernorm_param_grads(const float* __rest
         __syncthreads();
         __shared__ int arrived_last;
         if (threadIdx.x == 0) {
-            int* ticket = tickets + blockIdx.x;
+            int* ticket = a.tickets + block_x;
             const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = order == int(splits) - 1;
             if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -215,6 +231,22 @@ __global__ void __launch_bounds__(256) layernorm_param_grads(const float* __rest
         dw[c] = acc_w ? dw[c] + vw : vw;
         db[c] = acc_b ? db[c] + vb : vb;
     }
+}
+
+__global__ void __launch_bounds__(256) layernorm_param_grads(LnParamGrads a) {
+    layernorm_param_grads_body(a, int(blockIdx.x), blockIdx.y);
+}
+
+// the parameter gradients of several LayerNorms in one launch (queued while lg_gemm_group_* is open, see lg_layernorm_param_grads_f32)
+constexpr int kLnGroupMax = 8;
+struct LnParamGradsGroup {
+    LnParamGrads e[kLnGroupMax];
+    int          count;
+};
+__global__ void __launch_bounds__(256) layernorm_param_grads_group(LnParamGradsGroup grp) {
+    const LnParamGrads& a = grp.e[blockIdx.z];
+    if (int(blockIdx.x) >= a.blocks_x || int(blockIdx.y) >= a.splits) return;      // this entry's own grid is smaller
+    layernorm_param_grads_body(a, int(blockIdx.x), blockIdx.y);
 }
 
 // ---- cross entropy of softmax(logits) against integer labels (reference loss.py:14-24) ------------------------
@@ -529,6 +561,35 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     return LG_OK;
 }
 
+namespace lg {
+struct LnGroupState {
+    int               count = 0;
+    LnParamGradsGroup grp;
+    int64_t           tickets = 0;
+};
+static LnGroupState& ln_group() { static LnGroupState s; return s; }
+
+int ln_group_flush_pending() {
+    LnGroupState& S = ln_group();
+    if (S.count == 0) return LG_OK;
+    int rc = LG_OK;
+    if (S.count == 1) {
+        const LnParamGrads& a = S.grp.e[0];
+        hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(a.blocks_x), unsigned(a.splits)), dim3(256), 0, rt().stream, a);
+    } else {
+        int bx = 1, sp = 1;
+        for (int i = 0; i < S.count; ++i) { bx = S.grp.e[i].blocks_x > bx ? S.grp.e[i].blocks_x : bx; sp = S.grp.e[i].splits > sp ? S.grp.e[i].splits : sp; }
+        S.grp.count = S.count;
+        hipLaunchKernelGGL(layernorm_param_grads_group, dim3(unsigned(bx), unsigned(sp), unsigned(S.count)), dim3(256), 0, rt().stream, S.grp);
+    }
+    for (int i = 0; i < S.count; ++i)
+        if (S.grp.e[i].partial) { const int r = lg_free(S.grp.e[i].partial); if (r != LG_OK) rc = r; }       // stream-ordered
+    S.count = 0;
+    S.tickets = 0;
+    return rc;
+}
+}  // namespace lg
+
 extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, float* dw, float* db, int64_t rows, int64_t cols,
                                             int dw_accumulate, int db_accumulate) {
     LG_REQUIRE_INIT();
@@ -542,17 +603,38 @@ extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, f
         if (splits * 16 > rows) splits = rows / 16;            // ... with at least 16 rows each
         if (splits > 32) splits = 32;                          // ... and a short fold
         if (splits < 1) splits = 1;
-        if (blocks_x > rt().n_gemm_tickets) splits = 1;
+        if (blocks_x > rt().n_gemm_tickets / 2) splits = 1;
     }
     const int64_t chunk = rows > 0 ? (rows + splits - 1) / splits : 1;
     splits = rows > 0 ? (rows + chunk - 1) / chunk : 1;
-    float* partial = nullptr;
+    LnParamGrads a{};
+    a.g = g; a.xhat = xhat; a.dw = dw; a.db = db;
+    a.rows = rows; a.cols = cols; a.chunk = chunk;
+    a.blocks_x = int(blocks_x); a.splits = int(splits);
+    a.acc_w = dw_accumulate; a.acc_b = db_accumulate;
     if (splits > 1) {
-        int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(splits * 2 * cols) * sizeof(float));
+        int rc = lg_malloc(reinterpret_cast<void**>(&a.partial), size_t(splits * 2 * cols) * sizeof(float));
         if (rc != LG_OK) return rc;
     }
-    hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, rt().stream, g, xhat, dw, db,
-                       partial, rt().gemm_tickets, rows, cols, chunk, dw_accumulate, db_accumulate);
+    // While a gradient group is open (lg_gemm_group_begin) the launch is queued with the group's other work: the parameter
+    // gradients of all LayerNorms of a backward pass go out as ONE launch (7.5 us each alone, most of it launch + hand-off).
+    // Tickets: the upper half of the array, the GEMM group counts from the bottom.
+    LnGroupState& S = ln_group();
+    const bool queue = gemm_group_is_open() && blocks_x <= 64 && rows > 0;
+    if (queue) {
+        bool clash = false;
+        for (int i = 0; i < S.count; ++i) clash = clash || S.grp.e[i].dw == dw || S.grp.e[i].db == db;
+        if (clash || S.count == kLnGroupMax || S.tickets + blocks_x > rt().n_gemm_tickets / 2) {
+            const int rc = ln_group_flush_pending();
+            if (rc != LG_OK) return rc;
+        }
+        a.tickets = rt().gemm_tickets + rt().n_gemm_tickets / 2 + S.tickets;
+        S.tickets += blocks_x;
+        S.grp.e[S.count++] = a;
+        return LG_OK;
+    }
+    a.tickets = rt().gemm_tickets + rt().n_gemm_tickets / 2;
+    hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(blocks_x), unsigned(splits)), dim3(256), 0, rt().stream, a);
     LG_CHECK_LAUNCH();
-    return splits > 1 ? lg_free(partial) : LG_OK;
+    return splits > 1 ? lg_free(a.partial) : LG_OK;
 }

@@ -189,3 +189,74 @@ def test_parameter_gradients_accumulate_in_place(hip):
     tt.zero_grad()
     (tt[hip.from_numpy(ids, requires_grad=False)] * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
     np.testing.assert_allclose(2 * tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("how", ["group", "side_stream"])
+def test_parameter_gradients_off_the_critical_path(hip, how):
+    """a deep tape queues dW / db and LayerNorm's parameter gradients and launches them together at the end of the pass
+    (autograd/hip/tensor.py GradGroup, the default) or - on request - sends them to a second stream (SideStream): same
+    gradients as the plain single-stream pass - eager, accumulated over two passes, and replayed from a hipGraph - and no
+    memory stays parked afterwards"""
+    import gc
+    from lightgrad_amd.autograd.hip import HipGraph, HipDevice
+    from lightgrad_amd.autograd.hip.tensor import GradGroup, SideStream
+    from lightgrad_amd.dist import DataParallel, SingleProcess
+    rng = np.random.RandomState(5)
+    ids_np = rng.randint(0, 300, (4, 32)).astype(np.int32)
+    labels_np = rng.randint(0, 300, (4 * 32,)).astype(np.int64)
+
+    def build():
+        np.random.seed(9)
+        model = bert.BertForMaskedLM(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                     vocab_size=300, max_position_embeddings=32, type_vocab_size=2).map_parameters(lambda p: p.hip())
+        return model, DataParallel(model.parameters(), SingleProcess(), flatten=True)       # gradients = views of one bucket
+
+    ids, labels = hip.from_numpy(ids_np, requires_grad=False), hip.from_numpy(labels_np, requires_grad=False)
+
+    def one_pass(model, dp, zero=True):
+        loss = light.loss.cross_entropy(model(ids).reshape(-1, 300), labels)
+        if zero:
+            dp.bucket.fill(0)
+        loss.backward()
+        return loss
+
+    def configure(on):
+        GradGroup.enabled = on and how == "group"
+        SideStream.enabled = on and how == "side_stream"
+
+    defaults = (GradGroup.enabled, SideStream.enabled)
+    try:
+        results = {}
+        for mode in (False, True):
+            configure(mode)
+            model, dp = build()
+            one_pass(model, dp)
+            once = dp.bucket.numpy().copy()
+            one_pass(model, dp, zero=False)                      # second pass accumulates on top
+            results[mode] = (once, dp.bucket.numpy().copy())
+        assert np.abs(results[True][0]).max() > 0
+        for a, b in zip(results[True], results[False]):
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * np.abs(b).max())
+        # captured (the side brackets become branches of the graph): every replay gives the eager gradients again
+        configure(True)
+        model, dp = build()
+        one_pass(model, dp)
+        eager = dp.bucket.numpy().copy()
+        graph = HipGraph()
+        with graph.capture():
+            loss = one_pass(model, dp)
+        for _ in range(3):
+            graph.replay()
+            np.testing.assert_allclose(dp.bucket.numpy(), eager, rtol=1e-5, atol=1e-6 * np.abs(eager).max())
+        assert np.isfinite(loss.item())
+        graph.destroy()
+        del loss
+        in_use = []
+        for _ in range(3):
+            one_pass(model, dp)
+            HipDevice.synchronize()
+            gc.collect()
+            in_use.append(HipDevice.pool_stats()["in_use_bytes"])
+        assert in_use[2] == in_use[1], in_use                     # nothing stays parked or leaks per pass
+    finally:
+        GradGroup.enabled, SideStream.enabled = defaults

@@ -7,7 +7,8 @@ Differences from the reference, on purpose:
   * embeddings are looked up with `weight[ids]` on the tensor's own backend (the reference round-trips
     through the CPU and thereby drops the embedding gradient, bert.py:19-21);
   * `gelu` uses the backend's fused op when there is one (same expression, bert.py:12); so does the scaling of the
-    attention scores in front of their softmax (bert.py:81-86) when there is no mask to add in between.
+    attention scores in front of their softmax (bert.py:81-86) when there is no mask to add in between, and the two residual
+    additions of a layer (bert.py:101, :117), spelled `dense(h, residual=r)` (nn.Linear adds r where the product is made).
 
     python examples/bert.py [--cpu] [--batch 8]        # forward + backward of a random tiny-BERT
 """
@@ -104,7 +105,7 @@ class BertAttention(nn.Module):
 
     def forward(self, hidden_in, attention_mask=None):
         hidden, probs = self.self(hidden_in, attention_mask=attention_mask)
-        hidden = self.output.LayerNorm(self.output.dense(hidden) + hidden_in)
+        hidden = self.output.LayerNorm(self.output.dense(hidden, residual=hidden_in))     # dense(hidden) + hidden_in
         return hidden, probs
 
 
@@ -120,7 +121,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden, attention_mask=None):
         hidden, probs = self.attention(hidden, attention_mask)
-        hidden = hidden + self.output.dense(gelu(self.intermediate.dense(hidden)))
+        hidden = self.output.dense(gelu(self.intermediate.dense(hidden)), residual=hidden)  # hidden + dense(...)
         return self.output.LayerNorm(hidden), probs
 
 

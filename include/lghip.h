@@ -235,6 +235,14 @@ int lg_gemm_fused_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                       int accumulate, const float* bias, float* rowsum, int rowsum_accumulate,
                       int relu_a, int relu_b);
 
+/* C = (op(A) @ op(B) [+ bias]) + addend, addend an [M, N] matrix with row pitch ldadd (>= N) that may be C itself only
+ * through lg_gemm_f32's accumulate flag.  One matrix product.  The sums are formed in that order, each rounded to fp32 -
+ * the values of the separate bias add and residual add (`dense(h) + h_in`, reference examples/bert.py:101; a gradient that
+ * already holds a first contribution, autograd/tensor.py:111-118) without a pass over the result for either. */
+int lg_gemm_addend_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                       const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                       const float* bias, const float* addend, int64_t ldadd);
+
 /* lg_gemm_f32 over a TWO-level batch: matrix (o, i) of operand X starts at X + o*strideX_outer + i*strideX_inner.
  * One launch for attention-shaped products whose (batch, head) dims do not collapse into one stride after the head
  * split `reshape(b, s, h, d).transpose(0, 2, 1, 3)` (examples/bert.py:70-95; the reference's kernel is launched per

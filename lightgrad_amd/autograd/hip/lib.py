@@ -86,6 +86,8 @@ PROTOTYPES = {
                                       c_double, c_void_p, c_double, c_int, c_int]),
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "lg_gemm_addend_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, c_void_p, c_int64]),
     "lg_gemm_fused_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
     "lg_gemm_batched2_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,

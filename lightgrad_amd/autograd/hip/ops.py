@@ -330,7 +330,7 @@ def _product_layout(a, b, out_shape):
     return tuple(strides)
 
 
-def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=False, out_strides=None):
+def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=False, out_strides=None, addend=None):
     """a (..., M, K) @ b (..., K, N) [+ bias (N,)] -> (..., M, N) on the MFMA SGEMM kernel.
 
     Operands are consumed in place whenever one of their last two dims has stride 1
@@ -339,6 +339,8 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
     with a unit stride among the last two dims, see _layout_like) stores it in any such
     layout - so that a gradient can be produced directly in the layout of the tensor it
     belongs to and an attention product in the layout its consumer reshapes for free.
+    `addend` (dense, the shape of the result; one matrix product only) is added last:
+    (a @ b + bias) + addend from the GEMM's epilogue.
     """
     _require_f32(a, b)
     squeeze_a = squeeze_b = False
@@ -361,7 +363,10 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
             lead = _collapse_batch(a._shape[:-1], a._strides[:-1])
         rows, rstride = lead
         flat = HipTensor(a.data, (rows, K), (rstride if rows > 1 else K, a._strides[-1]), a._offset, a._dtype)
-        out = _gemm(flat, b, out_colmajor=False, bias=bias)
+        if addend is not None:
+            assert addend._shape == batch_shape + (M, N) and addend.is_contiguous()
+            addend = HipTensor(addend.data, (rows, N), None, addend._offset, addend._dtype)
+        out = _gemm(flat, b, out_colmajor=False, bias=bias, addend=addend)
         return out.reshape(*batch_shape, M, N)
 
     ma, mb = _as_mat(a), _as_mat(b)
@@ -410,8 +415,15 @@ def _gemm(a, b, out_colmajor=False, bias=None, accumulate_into=None, overwrite=F
     if bias is not None:
         assert not t_store and bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32
 
+    if addend is not None:
+        assert not batch_shape and not t_store and accumulate_into is None and K > 0
+        assert addend._shape == (M, N) and addend.is_contiguous() and addend._dtype == _F32
+
     def launch(pa, pb, po, count, stra, strb, stro):
-        if bias is not None:
+        if addend is not None:
+            _l.check(L.lg_gemm_addend_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K, pa, ma.ld, pb, mb.ld, po, ldc,
+                                          bias.ptr if bias is not None else None, addend.ptr, N))
+        elif bias is not None:
             _l.check(L.lg_gemm_bias_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K,
                                         pa, ma.ld, stra, pb, mb.ld, strb, po, ldc, stro, count, bias.ptr))
         elif t_store:
@@ -1077,8 +1089,17 @@ class linear(Function):
     Same values as the three-op form (transpose view, dot, broadcast add): the product is rounded to fp32 before the
     bias is added.  backward: dx = g @ W, dW = g^T @ x (dense, in W's own layout), db = column sums of g - what
     dot.backward + transpose.backward + the un-broadcast of func.py:50-56 produce. """
-    def forward(ctx, x, weight, bias=None):
+    def forward(ctx, x, weight, bias=None, residual=None):
         ctx.save_for_backward(x, weight, bias is not None)
+        if residual is not None:
+            # `dense(h) + h_in` (reference examples/bert.py:101, :117): the residual is added in the GEMM's epilogue - the
+            # values of the separate add, (x @ W^T + b) + residual, without its pass; its gradient is out_grad itself
+            assert residual._shape == x._shape[:-1] + (weight._shape[0],), "linear: residual %s for an output of %s" % (
+                residual._shape, x._shape[:-1] + (weight._shape[0],))
+            _require_f32(x, weight, residual)
+            if x.numel() > 0:
+                return _gemm(x, _swap_last(weight), bias=bias, addend=residual.contiguous())
+            return _binary(_l.EW_ADD, _gemm(x, _swap_last(weight), bias=bias), residual)
         pre = _lazy_relu_input(x)
         src = pre if pre is not None else x
         if _head_eligible(src, weight, bias):
@@ -1102,6 +1123,13 @@ class linear(Function):
         return _gemm(x, _swap_last(weight), bias=bias)
 
     def backward(ctx, out_grad):
+        grads = linear._backward(ctx, out_grad)
+        if len(ctx._parents) > 3 and ctx._parents[3] is not None:
+            # (x, weight, bias | None, residual): the residual's gradient is the output's
+            grads = tuple(grads) + (None,) * (3 - len(grads)) + (out_grad,)
+        return grads
+
+    def _backward(ctx, out_grad):
         x, weight, has_bias = ctx.get_saved_tensors()
         bias = ctx._parents[2] if has_bias else None
         out_f = weight._shape[0]
@@ -1188,6 +1216,19 @@ class linear(Function):
         if acc is not None and acc.is_contiguous() and len(x._shape) == 2:
             _gemm(g2, weight, accumulate_into=acc, overwrite=x._consume_zero_pending())
             (x._view_of_leaf if (x._view_of_leaf is not None and x._grad is None) else x)._notify_grad_written()
+            return (None,)
+        have = x._grad if (x._ctx is not None and x._view_of_leaf is None) else None
+        if (have is not None and have.__class__ is HipTensor and have._shape == x._shape and have._dtype == _F32
+                and have.is_contiguous() and g2._shape[0] > 0 and weight._shape[0] > 0):
+            # an intermediate that already holds a contribution (the residual branch, a sibling projection): what add_grad
+            # would do - `grad = grad + dx`, then `grad += dx` (tensor.py:111-118) - happens in this GEMM's epilogue
+            flat = HipTensor(have.data, (g2._shape[0], weight._shape[1]), None, have._offset, have._dtype)
+            if x._grad_shared:
+                x._grad = _gemm(g2, weight, addend=flat).reshape(*x._shape)      # the shared tensor stays untouched
+                x._grad._requires_grad = False
+                x._grad_shared = False
+            else:
+                _gemm(g2, weight, accumulate_into=flat)
             return (None,)
         return (_gemm(g2, weight).reshape(*x._shape),)
 

@@ -71,6 +71,10 @@ struct GemmArgs {
     int     nwg;            // tiles_m * tiles_n * batch * k_slices
     int     accumulate;
     const float* bias;      // optional [N]: added to every row of the product (nn.Linear's `+ b`, nn.py:96)
+    // optional [M, N] with row pitch ldadd, added last: C = (A @ B + bias) + addend - a residual connection
+    // (`dense(h) + h_in`, examples/bert.py:101) or a gradient that already exists (`grad + g @ W`) without a pass of its own
+    const float* addend;
+    int64_t      ldadd;
     // split-K: slice s of k_slices handles k in [s*k_per_slice, min(K, (s+1)*k_per_slice)) and writes its partial
     // tile to the workspace W (accumulator layout, see the kernel); the workgroup that arrives LAST at a tile
     // (per-tile ticket) sums the slices in index order - deterministic - and runs the epilogue
@@ -446,7 +450,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0,
                      int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0,
-                     int relu_a = 0, int relu_b = 0) {
+                     int relu_a = 0, int relu_b = 0, const float* addend = nullptr, int64_t ldadd = 0) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -456,6 +460,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
            "lg_gemm_f32: leading dimension too small (lda=%lld ldb=%lld ldc=%lld for M=%lld N=%lld K=%lld tA=%d tB=%d)",
            (long long)lda, (long long)ldb, (long long)ldc, (long long)M, (long long)N, (long long)K, transA, transB);
     LG_ARG(rowsum == nullptr || (batch == 1 && bias == nullptr), "lg_gemm_rowsum_f32: one matrix product, no bias");
+    LG_ARG(addend == nullptr || (batch == 1 && !accumulate && rowsum == nullptr && ldadd >= N && K > 0),
+           "lg_gemm_addend_f32: one matrix product with K > 0, no accumulate / row sums, ldadd >= N");
     if (K == 0) {
         LG_ARG(bias == nullptr, "lg_gemm_bias_f32: K == 0 with a bias is not supported");
         if (rowsum && !rowsum_accumulate) {
@@ -488,6 +494,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.batch_inner = int(batch_inner);
     g.accumulate = accumulate;
     g.bias = bias;
+    g.addend = addend;
+    g.ldadd = ldadd;
     g.rowsum = rowsum;
     g.rowsum_accumulate = rowsum_accumulate;
     g.k_tail = (K % 4 != 0) ? 1 : 0;
@@ -678,4 +686,11 @@ extern "C" int lg_gemm_group_end(void) {
     LG_ARG(G.active != 0, "lg_gemm_group_end: no group bracket is open");
     G.active = 0;                  // nothing is launched here: lg_gemm_group_flush does that
     return LG_OK;
+}
+
+extern "C" int lg_gemm_addend_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                  const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                  const float* bias, const float* addend, int64_t ldadd) {
+    LG_ARG(addend != nullptr, "lg_gemm_addend_f32: addend is NULL");
+    return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, 0, bias, nullptr, 0, 1, 0, 0, 0, 0, 0, addend, ldadd);
 }

@@ -123,12 +123,17 @@ class Linear(Module):
         self.weight = Tensor.xavier((out_feats, in_feats))
         self.bias = Tensor.xavier((out_feats,)) if bias else None
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` (extension of the reference's forward(x)): a tensor of the output's shape added to the result, as in
+        `dense(h) + h_in` of a transformer block - a backend with a fused op adds it where the product is made"""
         fused = getattr(x, "linear", None)
-        if fused is not None:        # one tape node, bias added in the GEMM epilogue (HipTensor)
+        if fused is not None:        # one tape node, bias (and residual) added in the GEMM epilogue (HipTensor)
+            if residual is not None:
+                return fused(self.weight, self.bias, residual)
             return fused(self.weight) if self.bias is None else fused(self.weight, self.bias)
         y = x @ self.weight.T(1, 0)
-        return y if self.bias is None else y + self.bias
+        y = y if self.bias is None else y + self.bias
+        return y if residual is None else y + residual
 
 
 class Conv2d(Module):

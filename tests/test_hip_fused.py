@@ -457,3 +457,39 @@ def test_scaled_softmax_is_the_two_kernel_form_bit_for_bit(hip):
         np.testing.assert_array_equal(x1.grad.numpy(), x2.grad.numpy())
         want = O.softmax_forward(xn * np.float32(scale), axis=-1)
         np.testing.assert_allclose(y1.numpy(), want, rtol=1e-5, atol=1e-7)
+
+
+def test_linear_with_residual_and_gradients_accumulated_in_the_input_product(hip):
+    """a transformer-shaped block: h feeds three Linear layers and a residual (`dense(z, residual=h)`), so h's gradient has
+    four contributions - on HipTensor the residual is added in the forward GEMM's epilogue and the second to fourth
+    contributions in the epilogues of the input-gradient GEMMs (no separate add kernels); values and every gradient against
+    the CPU backend's plain expressions"""
+    from lightgrad_amd import nn
+    rng = np.random.RandomState(41)
+    b, s, d = 3, 16, 24
+    xn, gn = rng.uniform(-1, 1, (b, s, d)).astype(np.float32), rng.uniform(-1, 1, (b, s, d)).astype(np.float32)
+    weights = [rng.uniform(-0.3, 0.3, (d, d)).astype(np.float32) for _ in range(5)]
+    biases = [rng.uniform(-0.3, 0.3, (d,)).astype(np.float32) for _ in range(5)]
+
+    def run(T):
+        layers = []
+        for w, bias in zip(weights, biases):
+            lin = nn.Linear(d, d)
+            lin.weight, lin.bias = T.from_numpy(w.copy()), T.from_numpy(bias.copy())
+            layers.append(lin)
+        x = T.from_numpy(xn)
+        h = layers[0](x)                                             # an intermediate: its gradient is built from 4 parts
+        z = layers[1](h) * layers[2](h) + layers[3](h)
+        out = layers[4](z, residual=h)
+        (out * T.from_numpy(gn, requires_grad=False)).backward(allow_fill=True)
+        grads = [x.grad.numpy(), h.grad.numpy()] + [p.grad.numpy() for lin in layers for p in (lin.weight, lin.bias)]
+        return [out.numpy()] + grads
+
+    for i, (got, want) in enumerate(zip(run(hip), run(CpuTensor))):
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6 * np.abs(want).max(), err_msg="result %d" % i)
+    # the C entry point: (A @ B^T + bias) + addend, bit for bit the three-step form
+    from lightgrad_amd.autograd.hip import ops as H
+    a, w, bias, r = (rng.uniform(-1, 1, sh).astype(np.float32) for sh in [(70, 33), (50, 33), (50,), (70, 50)])
+    fused = H._gemm(hip.from_numpy(a), H._swap_last(hip.from_numpy(w)), bias=hip.from_numpy(bias), addend=hip.from_numpy(r))
+    plain = H._gemm(hip.from_numpy(a), H._swap_last(hip.from_numpy(w)), bias=hip.from_numpy(bias)) + hip.from_numpy(r)
+    np.testing.assert_array_equal(fused.numpy(), plain.numpy())

@@ -328,73 +328,99 @@ __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restric
     }
 }
 
-// wide rows that fit the REGISTERS of one 1024-thread workgroup (cols <= 1024 * PER): the row is read from memory once -
-// maximum, exp and sum work on the held values (numpy's own order of operations: max, exp(x - max), sum, divide) and the
-// gradient is written straight from them.  BERT's (1024, 30522) logits: 83.6 -> see profiles/README.md r2.
-template <typename LabelT, int PER>
-__global__ void __launch_bounds__(1024) cross_entropy_held(const float* __restrict__ x, const LabelT* __restrict__ labels,
-                                                           float* __restrict__ dlogits, float* __restrict__ nll, int64_t cols,
-                                                           float inv_rows, int* status) {
-    __shared__ float red_m[16], red_s[16];
+// wide rows that one workgroup can HOLD in registers (cols <= THREADS * PER): the row is read from memory once - maximum, exp
+// and sum work on the held values (numpy's own order of operations: max, exp(x - max), sum, divide) and the gradient is
+// written straight from them.  Two shapes: 1024 threads x 8 / 16 values, and for a vocabulary 512 threads x 60 values - at 128
+// VGPRs a CU then holds TWO independent workgroups whose load, exp and store phases overlap.  BERT's (1024, 30522) logits,
+// back-to-back launches (tools/ce_bench.py): two-pass kernel 72.7 us, this one 58.6 us = 4.3 TB/s of logits read + gradient
+// written (61.4 without the line-aligned walk below).  Measured and not kept: a 2^x-based exp for non-positive arguments, 8
+// instructions instead of ~25 - 70.8 us, SLOWER: the kernel is bound by its memory phases, not by the exps.
+template <typename LabelT, int PER, int THREADS>
+__global__ void __launch_bounds__(THREADS, 4) cross_entropy_held(const float* __restrict__ x, const LabelT* __restrict__ labels,
+                                                                                        float* __restrict__ dlogits, float* __restrict__ nll,
+                                                                                        int64_t cols, float inv_rows, int* status) {
+    constexpr int WAVES = THREADS / 64;
+    __shared__ float red_m[WAVES], red_s[WAVES];
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xr = x + row * cols;
-    const int ncols = int(cols);                 // <= 1024 * PER
+    // A row starts wherever the previous one ended (30522 floats: 8-byte aligned at best).  The threads walk the row from
+    // the 128-byte line its first element lies in: every wave access then covers whole lines - unaligned, each 256-byte
+    // access touches three lines instead of two, for the reads and for the gradient writes alike.
+    const int off = int((row * cols) & 31);      // elements between that line's start and the row's first element
+    const float* xr = x + row * cols - off;
+    const int ncols = int(cols) + off;           // <= THREADS * PER; positions [off, ncols) are the row
     float v[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = i * 1024 + tid;
-        v[i] = c < ncols ? xr[c] : -INFINITY;
-    }
     float m = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) m = (v[i] > m || v[i] != v[i]) ? v[i] : m;
+    for (int i0 = 0; i0 < PER; i0 += 16) {
+#pragma unroll
+        for (int i = i0; i < i0 + 16 && i < PER; ++i) {
+            const int c = i * THREADS + tid;
+            v[i] = xr[c < ncols ? (c >= off ? c : off) : ncols - 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = i * THREADS + tid;
+        v[i] = (c >= off && c < ncols) ? v[i] : -INFINITY;
+        m = (v[i] > m || v[i] != v[i]) ? v[i] : m;
+    }
     m = wave_max(m);
     if (lane == 0) red_m[wave] = m;
     __syncthreads();
     float M = red_m[0];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) M = (red_m[w] > M || red_m[w] != red_m[w]) ? red_m[w] : M;
+    for (int w = 1; w < WAVES; ++w) M = (red_m[w] > M || red_m[w] != red_m[w]) ? red_m[w] : M;
     float s = 0.f;
+    static_assert(PER % 4 == 0, "four values at a time");
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = i * 1024 + tid;
-        v[i] = c < ncols ? expf(v[i] + (-M)) : 0.f;
-        s += v[i];
+    for (int i0 = 0; i0 < PER; i0 += 4) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) {
+            const int c = i * THREADS + tid;
+            v[i] = (c >= off && c < ncols) ? expf(v[i] + (-M)) : 0.f;
+            s += v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // four exps in flight, not all of them: their temporaries would not fit next to v[]
     }
     s = wave_sum(s);
     if (lane == 0) red_s[wave] = s;
     __syncthreads();
     float S = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) S += red_s[w];
+    for (int w = 0; w < WAVES; ++w) S += red_s[w];
     const float inv = 1.0f / S;
     int64_t label = int64_t(labels[row]);
     if (label < 0) label += cols;
     if (label < 0 || label >= cols) {
         if (tid == 0) { nll[row] = __builtin_nanf(""); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
-    const int ilabel = (label < 0 || label >= cols) ? -1 : int(label);
-    float* dr = dlogits + row * cols;
+    const int ilabel = (label < 0 || label >= cols) ? -1 : int(label) + off;
+    float* dr = dlogits + row * cols - off;
+    float p_label = -1.0f;                         // the probability at the label, for the one thread that holds it
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = i * 1024 + tid;
-        if (c < ncols) {
+    for (int i0 = 0; i0 < PER; i0 += 8) {
+#pragma unroll
+        for (int i = i0; i < i0 + 8 && i < PER; ++i) {
+            const int c = i * THREADS + tid;
             const float p = v[i] * inv;
-            dr[c] = (c == ilabel ? p - 1.0f : p) * inv_rows;
-            if (c == ilabel) nll[row] = -logf(p);
+            p_label = c == ilabel ? p : p_label;
+            if (c >= off && c < ncols) dr[c] = (c == ilabel ? p - 1.0f : p) * inv_rows;
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (p_label >= 0.0f || p_label != p_label) nll[row] = -logf(p_label);
 }
 
 template <typename LabelT>
 static void launch_cross_entropy_held(const float* logits, const LabelT* labels, float* dlogits, float* nll, int64_t rows, int64_t cols,
                                       float inv_rows) {
-    const dim3 grid{unsigned(rows)}, block(1024);
+    const dim3 grid{unsigned(rows)};
     hipStream_t s = rt().stream;
-    if (cols <= 1024 * 8)       hipLaunchKernelGGL((cross_entropy_held<LabelT, 8>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
-    else if (cols <= 1024 * 16) hipLaunchKernelGGL((cross_entropy_held<LabelT, 16>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
-    else                        hipLaunchKernelGGL((cross_entropy_held<LabelT, 32>), grid, block, 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    if (cols + 31 <= 1024 * 8)       hipLaunchKernelGGL((cross_entropy_held<LabelT, 8, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    else if (cols + 31 <= 1024 * 16) hipLaunchKernelGGL((cross_entropy_held<LabelT, 16, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    else                             hipLaunchKernelGGL((cross_entropy_held<LabelT, 60, 512>), grid, dim3(512), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
 }
 
 // ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
@@ -532,7 +558,7 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     const float inv_rows = float(1.0 / double(rows));
     hipStream_t s = rt().stream;
     static const char* ce_env = getenv("LG_CE_HELD");        // experiments only: 0 = the two-pass kernel for every width
-    if (cols >= 4096 && cols <= 1024 * 32 && rows < (int64_t(1) << 31) && !(ce_env && atoi(ce_env) == 0)) {
+    if (cols >= 4096 && cols + 31 <= 512 * 60 && rows < (int64_t(1) << 31) && !(ce_env && atoi(ce_env) == 0)) {
         // a vocabulary per row that fits one workgroup's registers: a single pass over memory
         if (label_itemsize == 2)      launch_cross_entropy_held(logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
         else if (label_itemsize == 4) launch_cross_entropy_held(logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows);

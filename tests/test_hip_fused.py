@@ -381,10 +381,10 @@ def test_bias_free_linear_waits_for_its_bias_row(hip):
 
 
 def test_cross_entropy_row_held_in_registers_widths(hip):
-    """widths on both sides of every register-count variant of the one-pass kernel (8 / 16 / 32 values per thread) and past
+    """widths on both sides of every variant of the one-pass kernel (1024 threads x 8 / 16 values, 512 x 60) and past
     its limit (two-pass kernel), bad labels included"""
     rng = np.random.RandomState(8)
-    for c in [4096, 8192, 8193, 12000, 16384, 16385, 32768, 32769]:
+    for c in [4096, 8161, 8162, 12000, 16353, 16354, 30522, 30689, 30690, 32769]:
         n = 5
         logits = rng.uniform(-6, 6, (n, c)).astype(np.float32)
         logits[1, c - 7:] = -np.inf

@@ -23,6 +23,12 @@ step hbm 200 "python tools/hbm_bench.py > $out/hbm_bench.txt 2>&1"; tail -3 $out
 step mlpgemm 100 "python tools/mlp_gemm_bench.py > $out/mlp_gemm_bench.txt 2>&1"; cat $out/mlp_gemm_bench.txt
 step headbench 100 "python tools/head_bench.py > $out/head_bench.txt 2>&1"; cat $out/head_bench.txt
 step timeline 100 "python tools/gemm_timeline.py > $out/gemm_timeline.txt 2>&1"; tail -3 $out/gemm_timeline.txt
+# tiny-BERT: one forward+backward kernel by kernel, the variants that were measured against it, its GEMM shapes, its loss kernel
+step berttrace 300 "rocprofv3 --kernel-trace --output-format csv -d $out/berttrace -- python3 tools/bert_bench.py --replays 6 > $out/berttrace.log 2>&1"
+python tools/bert_bench.py --trace $out/berttrace/*/*_kernel_trace.csv > $out/bert_step_trace.txt; tail -30 $out/bert_step_trace.txt
+step bertbench 200 "python tools/bert_bench.py > $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 (weight gradients launched where the tape makes them, dW and dx paired)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 (weight gradients on a second stream: parallel branches of the hipGraph)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1"; cat $out/bert_bench.txt
+step bertgemm 100 "python tools/bert_gemm_bench.py > $out/bert_gemm_bench.txt 2>&1"; cat $out/bert_gemm_bench.txt
+step cebench 100 "python tools/ce_bench.py > $out/ce_bench.txt 2>&1; LG_CE_HELD=0 python tools/ce_bench.py >> $out/ce_bench.txt 2>&1"; cat $out/ce_bench.txt
 # SQ counters of the six MLP GEMM shapes + the head kernels (one counter pair per pass)
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do

@@ -83,216 +83,83 @@ class reshape(Function):
         return out_grad.reshape(shape)
 
 
-""" Basic math """
+""" Element-wise arithmetic, matrix product, non-linearities
+
+One table instead of one class per op: each row gives the value and the gradients as plain numpy expressions - the
+reference's own (cpu/ops.py:52-116, :158-229; operand order kept, so results are its bits) - and says what the backward needs
+kept.  `_formula_op` turns a row into a tape node. """
+
+_KEEP_NOTHING, _KEEP_INPUTS, _KEEP_OUTPUT, _KEEP_BOTH = range(4)
 
 
-@_op()
-class neg(Function):
-    """ cpu/ops.py:52-58 """
-    def forward(ctx, a):
-        return -a
-
-    def backward(ctx, out_grad):
-        return -out_grad
-
-
-@_op()
-class add(Function):
-    """ cpu/ops.py:60-66 """
-    def forward(ctx, a, b):
-        return a + b
-
-    def backward(ctx, out_grad):
-        return out_grad, out_grad
-
-
-@_op(overwrite=True)
-class sub(Function):
-    """ first-class by name only; the `-` operator stays the composite (cpu/ops.py:68-74) """
-    def forward(ctx, a, b):
-        return a - b
-
-    def backward(ctx, out_grad):
-        return out_grad, -out_grad
-
-
-@_op()
-class mul(Function):
-    """ cpu/ops.py:76-84 """
-    def forward(ctx, a, b):
-        ctx.save_for_backward(a, b)
-        return a * b
-
-    def backward(ctx, out_grad):
-        a, b = ctx.get_saved_tensors()
-        return out_grad * b, a * out_grad
-
-
-@_op(overwrite=True)
-class div(Function):
-    """ cpu/ops.py:86-94 """
-    def forward(ctx, a, b):
-        ctx.save_for_backward(a, b)
-        return a / b
-
-    def backward(ctx, out_grad):
-        a, b = ctx.get_saved_tensors()
-        return out_grad / b, -a / b**2 * out_grad
-
-
-@_op()
-class pow(Function):
-    """ cpu/ops.py:96-105; the exponent gradient is always formed (NaN for a<0, as in the reference) """
-    def forward(ctx, a, b):
-        y = a ** b
-        ctx.save_for_backward(a, b, y)
+def _formula_op(name, value, gradients, keep, aliases=(), overwrite=False, cite=""):
+    def forward(ctx, *inputs):
+        y = value(*inputs)
+        if keep == _KEEP_INPUTS:
+            ctx.save_for_backward(*inputs)
+        elif keep == _KEEP_OUTPUT:
+            ctx.save_for_backward(y)
+        elif keep == _KEEP_BOTH:
+            ctx.save_for_backward(*(inputs + (y,)))
         return y
 
     def backward(ctx, out_grad):
-        a, b, y = ctx.get_saved_tensors()
-        with np.errstate(invalid='ignore', divide='ignore'):
-            return b * (a ** (b - 1)) * out_grad, out_grad * y * np.log(a)
+        return gradients(out_grad, *ctx.get_saved_tensors())
+
+    node = type(name, (Function,), {"forward": forward, "backward": backward, "__doc__": cite})
+    return _op(*((name,) + tuple(aliases)), overwrite=overwrite)(node)
 
 
-@_op("__matmul__", "dot")
-class dot(Function):
-    """ a @ b (cpu/ops.py:107-116); backward swaps the last two axes so that it is also
-    right for batched operands (opencl/ops.py:127-132) - identical to `.T` in 2-D """
-    def forward(ctx, a, b):
-        ctx.save_for_backward(a, b)
-        return a @ b
-
-    def backward(ctx, out_grad):
-        a, b = ctx.get_saved_tensors()
-        return out_grad @ np.swapaxes(b, -1, -2), np.swapaxes(a, -1, -2) @ out_grad
+def _last_two_swapped(m):
+    return np.swapaxes(m, -1, -2)
 
 
-""" In-place operators: no backward, result aliases the input storage (cpu/ops.py:120-153) """
+def _pow_gradients(g, a, b, y):
+    # the exponent's gradient is always formed (NaN for a < 0, as in the reference, cpu/ops.py:101-105)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return b * (a ** (b - 1)) * g, g * y * np.log(a)
 
 
-@_op("__iadd__", overwrite=True)
-class iadd(Function):
+_FORMULAS = [
+    # name        value                                  gradients(g, *kept)                                   kept            extra
+    ("neg",       lambda a: -a,                          lambda g: -g,                                          _KEEP_NOTHING,  {}),
+    ("add",       lambda a, b: a + b,                    lambda g: (g, g),                                      _KEEP_NOTHING,  {}),
+    ("sub",       lambda a, b: a - b,                    lambda g: (g, -g),                                     _KEEP_NOTHING,  {"overwrite": True}),
+    ("mul",       lambda a, b: a * b,                    lambda g, a, b: (g * b, a * g),                        _KEEP_INPUTS,   {}),
+    ("div",       lambda a, b: a / b,                    lambda g, a, b: (g / b, -a / b**2 * g),                _KEEP_INPUTS,   {"overwrite": True}),
+    ("pow",       lambda a, b: a ** b,                   _pow_gradients,                                        _KEEP_BOTH,     {}),
+    # a @ b; the backward swaps the last two axes so that it is also right for batched operands (opencl/ops.py:127-132)
+    ("dot",       lambda a, b: a @ b,                    lambda g, a, b: (g @ _last_two_swapped(b), _last_two_swapped(a) @ g),
+                                                                                                                _KEEP_INPUTS,   {"aliases": ("__matmul__",)}),
+    ("sin",       np.sin,                                lambda g, t: np.cos(t) * g,                            _KEEP_INPUTS,   {}),
+    ("cos",       np.cos,                                lambda g, t: -np.sin(t) * g,                           _KEEP_INPUTS,   {}),
+    ("exp",       np.exp,                                lambda g, y: y * g,                                    _KEEP_OUTPUT,   {}),
+    ("log",       np.log,                                lambda g, x: (1 / x) * g,                              _KEEP_INPUTS,   {}),
+    ("sigmoid",   lambda t: 1 / (1 + np.exp(-t)),        lambda g, y: y * (1 - y) * g,                          _KEEP_OUTPUT,   {"overwrite": True}),
+    ("tanh",      np.tanh,                               lambda g, y: (1 - y**2) * g,                           _KEEP_OUTPUT,   {"overwrite": True}),
+    # the gradient passes at exactly 0 (cpu/ops.py:221-229)
+    ("relu",      lambda t: np.maximum(t, 0.0),          lambda g, t: g * (t >= 0),                             _KEEP_INPUTS,   {}),
+]
+for _name, _value, _gradients, _keep, _extra in _FORMULAS:
+    globals()[_name] = _formula_op(_name, _value, _gradients, _keep, cite="reference cpu/ops.py, op `%s`" % _name, **_extra)
+
+
+""" In-place operators and fill: no backward, the result IS the input's storage (cpu/ops.py:120-153) """
+
+
+def _in_place_op(name, apply, registered_as=None):
     def forward(ctx, t, other):
-        t += other
+        apply(t, other)
         return t
+    node = type(name, (Function,), {"forward": forward})          # the class name shows in "Cannot Backward through <name>!"
+    return _op(registered_as or name, overwrite=True)(node)
 
 
-@_op("__isub__", overwrite=True)
-class isub(Function):
-    def forward(ctx, t, other):
-        t -= other
-        return t
-
-
-@_op("__imul__", overwrite=True)
-class imul(Function):
-    def forward(ctx, t, other):
-        t *= other
-        return t
-
-
-@_op("__itruediv__", overwrite=True)
-class itruediv(Function):
-    def forward(ctx, t, other):
-        t /= other
-        return t
-
-
-@_op()
-class fill(Function):
-    def forward(ctx, t, val):
-        t.fill(val)
-        return t
-
-
-""" Non-linearities """
-
-
-@_op()
-class sin(Function):
-    """ cpu/ops.py:158-166 """
-    def forward(ctx, t):
-        ctx.save_for_backward(t)
-        return np.sin(t)
-
-    def backward(ctx, out_grad):
-        t, = ctx.get_saved_tensors()
-        return np.cos(t) * out_grad
-
-
-@_op()
-class cos(Function):
-    """ cpu/ops.py:168-176 """
-    def forward(ctx, t):
-        ctx.save_for_backward(t)
-        return np.cos(t)
-
-    def backward(ctx, out_grad):
-        t, = ctx.get_saved_tensors()
-        return -np.sin(t) * out_grad
-
-
-@_op()
-class exp(Function):
-    """ saves the output (cpu/ops.py:178-187) """
-    def forward(ctx, t):
-        y = np.exp(t)
-        ctx.save_for_backward(y)
-        return y
-
-    def backward(ctx, out_grad):
-        y, = ctx.get_saved_tensors()
-        return y * out_grad
-
-
-@_op()
-class log(Function):
-    """ cpu/ops.py:189-197 """
-    def forward(ctx, t):
-        ctx.save_for_backward(t)
-        return np.log(t)
-
-    def backward(ctx, out_grad):
-        x, = ctx.get_saved_tensors()
-        return (1 / x) * out_grad
-
-
-@_op(overwrite=True)
-class sigmoid(Function):
-    """ cpu/ops.py:199-208 """
-    def forward(ctx, t):
-        y = 1 / (1 + np.exp(-t))
-        ctx.save_for_backward(y)
-        return y
-
-    def backward(ctx, out_grad):
-        y, = ctx.get_saved_tensors()
-        return y * (1 - y) * out_grad
-
-
-@_op(overwrite=True)
-class tanh(Function):
-    """ cpu/ops.py:210-219 """
-    def forward(ctx, t):
-        y = np.tanh(t)
-        ctx.save_for_backward(y)
-        return y
-
-    def backward(ctx, out_grad):
-        y, = ctx.get_saved_tensors()
-        return (1 - y**2) * out_grad
-
-
-@_op()
-class relu(Function):
-    """ gradient passes at exactly 0 (cpu/ops.py:221-229) """
-    def forward(ctx, t):
-        ctx.save_for_backward(t)
-        return np.maximum(t, 0.0)
-
-    def backward(ctx, out_grad):
-        t, = ctx.get_saved_tensors()
-        return out_grad * (t >= 0)
+iadd = _in_place_op("iadd", lambda t, other: t.__iadd__(other), "__iadd__")
+isub = _in_place_op("isub", lambda t, other: t.__isub__(other), "__isub__")
+imul = _in_place_op("imul", lambda t, other: t.__imul__(other), "__imul__")
+itruediv = _in_place_op("itruediv", lambda t, other: t.__itruediv__(other), "__itruediv__")
+fill = _in_place_op("fill", lambda t, value: t.fill(value))
 
 
 """ Selectors """

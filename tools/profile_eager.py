@@ -39,6 +39,23 @@ def step():
     opt.step()
 
 
+if "--bert" in sys.argv:
+    # tiny-BERT forward + backward as bench.py runs it (batch 8 x 128, masked-LM cross-entropy)
+    import importlib.util
+    sys.argv.remove("--bert")
+    spec = importlib.util.spec_from_file_location("bert_example", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bert.py"))
+    bert = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bert)
+    bmodel = bert.BertForMaskedLM(**bert.TINY).map_parameters(lambda p: p.hip())
+    ids = HipTensor.from_numpy(np.random.randint(0, 30522, (8, 128)).astype(np.int32), requires_grad=False)
+    labels = HipTensor.from_numpy(np.random.randint(0, 30522, (8 * 128,)).astype(np.int64), requires_grad=False)
+    bdp = DataParallel(bmodel.parameters(), SingleProcess(), flatten=True)
+
+    def step():                                                   # noqa: F811
+        loss = light.loss.cross_entropy(bmodel(ids).reshape(-1, 30522), labels)
+        bdp.bucket.fill(0)
+        loss.backward()
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 for _ in range(50):
     step()

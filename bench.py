@@ -50,9 +50,11 @@ def parse():
                     help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
                     help="graph: the step's kernels are captured once in hipGraphs and replayed; eager: python tape every step")
-    ap.add_argument("--comm-dispatch", choices=["graph", "eager"], default="graph",
-                    help="N > 1: graph = the all-reduce is a forked branch INSIDE the captured step (no host call per step); "
-                         "eager = forward+backward replay from a graph, all-reduce and optimizer are host calls")
+    ap.add_argument("--comm-dispatch", choices=["auto", "graph", "graph-inline", "eager"], default="auto",
+                    help="N > 1, where the gradient all-reduce runs: graph = a forked branch INSIDE the captured step, overlapped "
+                         "with the input-gradient GEMM (no host call per step); graph-inline = inside the captured step on the "
+                         "compute stream (no branch, no overlap); eager = forward+backward replay from a graph, all-reduce and "
+                         "optimizer are host calls; auto = time a short run of each and keep the fastest (all ranks agree)")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="training steps recorded per hipGraph (each one complete: forward, backward, exchange, update); a replay "
                          "boundary costs ~8 us of idle GPU, so several steps per graph amortise it.  1 = one step per replay")
@@ -211,14 +213,17 @@ def gpu_rank(args, rank, world):
         def forward(self, x):
             return self.l2(self.l1(x.reshape(-1, 784)).relu())
 
-    def mlp_leg(comm_dispatch):
-        """build model / optimizer / graphs and time the training step; raises if a capture fails or the replicas diverge"""
+    def mlp_leg(comm_dispatch, n_steps=None, n_warmup=None, quick=False):
+        """build model / optimizer / graphs and time the training step; raises if a capture fails or the replicas diverge.
+        quick: a calibration run - only the timed steps, none of the side measurements"""
+        n_steps = args.steps if n_steps is None else n_steps
+        n_warmup = args.warmup if n_warmup is None else n_warmup
         np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
         model = MLP()
         w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
         model.map_parameters(lambda p: p.hip())
         use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
-        overlap = multi and not (use_graph and comm_dispatch == "eager")
+        overlap = multi and (comm_dispatch == "graph" or not use_graph)
         dp = DataParallel(model.parameters(), comm, flatten=use_graph, overlap=overlap)
         dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
         opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
@@ -254,9 +259,10 @@ def gpu_rank(args, rank, world):
         if use_graph:
             n_params = len(opt.parameters)
             g_all = None
-            if not multi or comm_dispatch == "graph":
-                # ONE graph for the whole step.  With a communicator the all-reduce is a forked branch of it: started on the
-                # communication stream after the last parameter-gradient kernel, joined before the optimizer kernel.
+            if not multi or comm_dispatch in ("graph", "graph-inline"):
+                # ONE graph for the whole step.  With a communicator the all-reduce is part of it - as a forked branch (started on
+                # the communication stream after the last parameter-gradient kernel, joined before the optimizer kernel) or, with
+                # graph-inline, as one more node of the chain on the compute stream.
                 try:
                     g_all = HipGraph()
                     with g_all.capture():
@@ -273,8 +279,8 @@ def gpu_rank(args, rank, world):
                 # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
                 # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
                 # on the resident batch; the timed loop below still performs exactly --steps of them.
-                unroll = max(1, min(args.graph_steps, args.steps))
-                while args.steps % unroll:
+                unroll = max(1, min(args.graph_steps, n_steps))
+                while n_steps % unroll:
                     unroll -= 1
                 if unroll > 1:
                     g_multi = HipGraph()
@@ -295,7 +301,7 @@ def gpu_rank(args, rank, world):
                     opt.step()
                     return graph_loss
 
-        for _ in range(args.warmup):
+        for _ in range(n_warmup):
             loss = step()
         if unroll > 1:
             g_multi.replay()                             # untimed: first launch of the multi-step graph
@@ -303,26 +309,28 @@ def gpu_rank(args, rank, world):
         fence()
         t0 = time.perf_counter()
         if unroll > 1:
-            for _ in range(args.steps // unroll):
+            for _ in range(n_steps // unroll):
                 g_multi.replay()
                 opt.on_graph_replay(unroll)
             loss = multi_loss
         else:
-            for _ in range(args.steps):
+            for _ in range(n_steps):
                 loss = step()
         fence()
         mine = time.perf_counter() - t0
         elapsed = wall_max(mine)
-        per_rank = gather(args.steps / mine)
+        per_rank = gather(n_steps / mine)
         final_loss = loss.item()
         assert np.isfinite(final_loss), final_loss
-        steps_per_s = world * args.steps / elapsed
+        steps_per_s = world * n_steps / elapsed
         digest = dp.parameter_digest()
         if multi:                                        # replicas must still be identical
             d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
             comm.allreduce_max_(d)
             dmax, dmin = d.numpy()
             assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
+        if quick:
+            return dict(steps_per_s=steps_per_s)
 
         # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
         eager_steps = max(10, min(args.steps, 100))
@@ -366,20 +374,39 @@ def gpu_rank(args, rank, world):
                     eager_steps_per_s=eager_steps_per_s, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
                     unroll=unroll, use_graph=use_graph, overlap=dp.overlap, w0=w0, x_np=x_np, onehot_np=onehot_np)
 
-    # The exchange inside the captured graph is the design; should capturing the collective fail, or the replicas
-    # come out different after the timed steps, the whole leg is repeated with host-launched collectives and that is reported.
-    modes = ["graph", "eager"] if (multi and args.comm_dispatch == "graph") else [args.comm_dispatch]
-    R, fallback_reason = None, None
+    # Where the all-reduce runs is decided by measurement (--comm-dispatch auto): a short run of every form, the fastest one -
+    # by the slowest rank's clock, so every rank picks the same - is then timed in full.  The forked branch inside the captured
+    # step is the design, but what a branch costs in a replayed hipGraph is a property of the runtime, not of
+    # this code.  A form whose capture fails, or whose replicas come out different, drops out; so does the chosen one if it
+    # fails in the full run (the next best is taken).
+    calibration = {}
+    if multi and args.comm_dispatch == "auto":
+        candidates = ["graph", "graph-inline", "eager"]
+        for mode in candidates:
+            try:
+                quick_steps = max(args.graph_steps, 5 * args.graph_steps)
+                calibration[mode] = round(mlp_leg(mode, n_steps=quick_steps, n_warmup=min(args.warmup, 10), quick=True)["steps_per_s"], 1)
+            except (L.HipError, AssertionError) as e:
+                calibration[mode] = "failed: %s: %s" % (type(e).__name__, e)
+                sys.stderr.write("[bench] rank %d: exchange form %r failed in calibration (%s)\n" % (rank, mode, calibration[mode]))
+        modes = sorted((m for m in candidates if not isinstance(calibration[m], str)), key=lambda m: -calibration[m])
+        assert modes, "no form of the gradient exchange works: %r" % (calibration,)
+    elif multi and args.comm_dispatch == "graph":
+        modes = ["graph", "eager"]
+    else:
+        modes = [args.comm_dispatch if multi else "graph"]
+    R, fallback_reason, chosen = None, None, None
     for k, mode in enumerate(modes):
         try:
             R = mlp_leg(mode)
+            chosen = mode
             break
         except (L.HipError, AssertionError) as e:
             if k == len(modes) - 1:
                 raise
-            fallback_reason = "%s: %s" % (type(e).__name__, e)
-            sys.stderr.write("[bench] rank %d: the leg with the in-graph exchange failed (%s); repeating with host-launched collectives\n"
-                             % (rank, fallback_reason))
+            fallback_reason = "%s: %s: %s" % (mode, type(e).__name__, e)
+            sys.stderr.write("[bench] rank %d: the leg with exchange form %r failed (%s); repeating with %r\n"
+                             % (rank, mode, fallback_reason, modes[k + 1]))
     steps_per_s, elapsed, per_rank, final_loss, first_losses = (R[k] for k in ("steps_per_s", "elapsed", "per_rank", "final_loss", "first_losses"))
     eager_steps_per_s, data_input_steps_per_s, comm_in_graph, unroll, use_graph = (
         R[k] for k in ("eager_steps_per_s", "data_input_steps_per_s", "comm_in_graph", "unroll", "use_graph"))
@@ -391,9 +418,12 @@ def gpu_rank(args, rank, world):
                   "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else
                               ("torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"),
                   "exchange": None if not multi else
-                              ("all-reduce forked inside the captured step, overlapped with the input-gradient GEMM" if comm_in_graph else
-                               ("host-launched all-reduce on the communication stream, overlapped" if R["overlap"] else
-                                "host-launched all-reduce on the compute stream after backward")),
+                              {"graph": "all-reduce forked inside the captured step, overlapped with the input-gradient GEMM",
+                               "graph-inline": "all-reduce inside the captured step on the compute stream (no branch, no overlap)",
+                               "eager": "host-launched all-reduce after the replayed forward+backward graph"}.get(chosen, chosen)
+                              if use_graph else "host-launched all-reduce on the communication stream, overlapped with backward (eager tape)",
+                  "exchange_form": chosen if multi else None,
+                  "exchange_calibration_steps_per_sec": calibration or None,
                   "in_graph_exchange_fallback": fallback_reason}
 
     out = {

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/lghip.h"
 #include "../../include/lghip_comm.h"
 
@@ -101,12 +102,21 @@ int lg_comm_rank(int* rank, int* nranks) {
     return LG_OK;
 }
 
+// experiments only (LG_COMM_DEBUG_KERNEL=1): a one-wave kernel behind every collective, on the collective's stream.  With ONE
+// rank ncclAllReduce in place enqueues nothing, so a captured "forked" exchange is an empty branch and says nothing about what
+// a branch with a kernel in it costs in a hipGraph; this makes the branch real on a single-GPU box (bench.py --force-comm).
+__global__ void comm_debug_touch(float* buf) {
+    if (threadIdx.x == 0) buf[0] = buf[0] * 1.0f;
+}
+
 static int allreduce_on(hipStream_t stream, float* buf, int64_t n, int op, const char* who) {
     if (!g_comm) { cerr("%s: communicator not initialised", who); return LG_ENOTINIT; }
     if (n < 0 || (n > 0 && !buf)) { cerr("%s: bad buffer", who); return LG_EINVAL; }
     if (op != LG_COMM_SUM && op != LG_COMM_MAX) { cerr("%s: unknown op %d", who, op); return LG_EINVAL; }
     if (n == 0) return LG_OK;
     LG_NCCL(ncclAllReduce(buf, buf, size_t(n), ncclFloat32, op == LG_COMM_SUM ? ncclSum : ncclMax, g_comm, stream));
+    static const char* dbg = getenv("LG_COMM_DEBUG_KERNEL");
+    if (dbg && atoi(dbg) == 1) hipLaunchKernelGGL(comm_debug_touch, dim3(1), dim3(64), 0, stream, buf);
     return LG_OK;
 }
 

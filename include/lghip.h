@@ -410,6 +410,11 @@ int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, int id_items
  * the loss is mean(nll) (lg_reduce + one scalar multiply), its gradient dlogits * upstream. */
 int lg_cross_entropy_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
                          int64_t rows, int64_t cols);
+/* The same plus the loss itself: mean[0] = (sum of nll) * (1 / rows), as `loss.cross_entropy` returns it (loss.py:21).  For
+ * vocabulary-sized rows the mean is formed inside the row kernel (the workgroup that finishes last sums the row losses in a
+ * fixed order); otherwise by the generic reduction + scaling behind it. */
+int lg_cross_entropy_mean_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                              float* mean, int64_t rows, int64_t cols);
 
 /* library build info: "liblghip <version> gfx950 <build date>" */
 const char* lg_version(void);

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),
     "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_cross_entropy_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64]),
+    "lg_cross_entropy_mean_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_layernorm_param_grads_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int]),
     "lg_take_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "lg_put_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_uint64]),

@@ -1542,9 +1542,12 @@ def cross_entropy_forward(y, labels):
     y, labels = y.contiguous(), labels.contiguous()
     n, c = y._shape
     dlogits, nll = HipTensor.empty(y._shape), HipTensor.empty((n,))
-    _l.check(_l.lib().lg_cross_entropy_f32(y.ptr, labels.ptr, labels._dtype.itemsize, dlogits.ptr, nll.ptr, n, c))
-    total = _reduce(_l.RED_SUM, nll, (0,), False)
-    loss = _ew(_l.EW_MUL, (), [total, None], scalar=1.0 / n)
+    if n == 0:
+        _l.check(_l.lib().lg_cross_entropy_f32(y.ptr, labels.ptr, labels._dtype.itemsize, dlogits.ptr, nll.ptr, n, c))
+        total = _reduce(_l.RED_SUM, nll, (0,), False)
+        return _ew(_l.EW_MUL, (), [total, None], scalar=float("nan")), dlogits          # mean of nothing
+    loss = HipTensor.empty(())
+    _l.check(_l.lib().lg_cross_entropy_mean_f32(y.ptr, labels.ptr, labels._dtype.itemsize, dlogits.ptr, nll.ptr, loss.ptr, n, c))
     return loss, dlogits
 
 

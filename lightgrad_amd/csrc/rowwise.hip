@@ -337,8 +337,8 @@ __global__ void __launch_bounds__(256) cross_entropy_wide(const float* __restric
 // instructions instead of ~25 - 70.8 us, SLOWER: the kernel is bound by its memory phases, not by the exps.
 template <typename LabelT, int PER, int THREADS>
 __global__ void __launch_bounds__(THREADS, 4) cross_entropy_held(const float* __restrict__ x, const LabelT* __restrict__ labels,
-                                                                                        float* __restrict__ dlogits, float* __restrict__ nll,
-                                                                                        int64_t cols, float inv_rows, int* status) {
+                                                                 float* __restrict__ dlogits, float* nll, int64_t cols, float inv_rows,
+                                                                 int* status, float* mean_out, int* ticket) {
     constexpr int WAVES = THREADS / 64;
     __shared__ float red_m[WAVES], red_s[WAVES];
     const int64_t row = blockIdx.x;
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(THREADS, 4) cross_entropy_held(const float* __
     int64_t label = int64_t(labels[row]);
     if (label < 0) label += cols;
     if (label < 0 || label >= cols) {
-        if (tid == 0) { nll[row] = __builtin_nanf(""); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        if (tid == 0) { __hip_atomic_store(nll + row, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
     const int ilabel = (label < 0 || label >= cols) ? -1 : int(label) + off;
     float* dr = dlogits + row * cols - off;
@@ -410,17 +410,48 @@ __global__ void __launch_bounds__(THREADS, 4) cross_entropy_held(const float* __
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (p_label >= 0.0f || p_label != p_label) nll[row] = -logf(p_label);
+    // per-row losses are published write-through: the workgroup that arrives LAST reads all of them for the mean (below)
+    if (p_label >= 0.0f || p_label != p_label) __hip_atomic_store(nll + row, -logf(p_label), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mean_out == nullptr) return;
+    // mean over rows inside this launch (saves the reduction + scaling launches behind it): drain, take a ticket, the last
+    // workgroup sums the row losses in a fixed order - thread t takes rows t, t + THREADS, ...; waves, then the workgroup, in
+    // index order - and multiplies by 1/rows like the two-kernel form
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int arrived_last;
+    if (tid == 0) {
+        const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = order == int(gridDim.x) - 1;
+        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived_last = last;
+    }
+    __syncthreads();
+    if (!arrived_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float total = 0.f;
+    for (int64_t i = tid; i < int64_t(gridDim.x); i += THREADS)
+        total += __hip_atomic_load(nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    total = wave_sum(total);
+    __syncthreads();                             // red_s is free again
+    if (lane == 0) red_s[wave] = total;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) t += red_s[w];
+        mean_out[0] = t * inv_rows;
+    }
 }
 
 template <typename LabelT>
 static void launch_cross_entropy_held(const float* logits, const LabelT* labels, float* dlogits, float* nll, int64_t rows, int64_t cols,
-                                      float inv_rows) {
+                                      float inv_rows, float* mean_out) {
     const dim3 grid{unsigned(rows)};
     hipStream_t s = rt().stream;
-    if (cols + 31 <= 1024 * 8)       hipLaunchKernelGGL((cross_entropy_held<LabelT, 8, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
-    else if (cols + 31 <= 1024 * 16) hipLaunchKernelGGL((cross_entropy_held<LabelT, 16, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
-    else                             hipLaunchKernelGGL((cross_entropy_held<LabelT, 60, 512>), grid, dim3(512), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev);
+    int* ticket = rt().gemm_tickets + rt().n_gemm_tickets - 1;          // the last slot: nobody else counts that far
+    if (cols + 31 <= 1024 * 8)       hipLaunchKernelGGL((cross_entropy_held<LabelT, 8, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev, mean_out, ticket);
+    else if (cols + 31 <= 1024 * 16) hipLaunchKernelGGL((cross_entropy_held<LabelT, 16, 1024>), grid, dim3(1024), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev, mean_out, ticket);
+    else                             hipLaunchKernelGGL((cross_entropy_held<LabelT, 60, 512>), grid, dim3(512), 0, s, logits, labels, dlogits, nll, cols, inv_rows, rt().status_dev, mean_out, ticket);
 }
 
 // ---- embedding: out[i, :] = table[ids[i], :] ; grad_table[ids[i], :] += grad_out[i, :] -------------------------
@@ -547,8 +578,9 @@ extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, i
     return LG_OK;
 }
 
-extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
-                                    int64_t rows, int64_t cols) {
+static int cross_entropy_impl(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                              int64_t rows, int64_t cols, float* mean_out, bool* mean_done) {
+    *mean_done = false;
     LG_REQUIRE_INIT();
     LG_ARG(label_itemsize == 2 || label_itemsize == 4 || label_itemsize == 8, "lg_cross_entropy_f32: labels must be int16/int32/int64");
     LG_ARG(rows >= 0 && cols >= 1, "lg_cross_entropy_f32: bad shape");
@@ -560,9 +592,10 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
     static const char* ce_env = getenv("LG_CE_HELD");        // experiments only: 0 = the two-pass kernel for every width
     if (cols >= 4096 && cols + 31 <= 512 * 60 && rows < (int64_t(1) << 31) && !(ce_env && atoi(ce_env) == 0)) {
         // a vocabulary per row that fits one workgroup's registers: a single pass over memory
-        if (label_itemsize == 2)      launch_cross_entropy_held(logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows);
-        else if (label_itemsize == 4) launch_cross_entropy_held(logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows);
-        else                          launch_cross_entropy_held(logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows);
+        if (label_itemsize == 2)      launch_cross_entropy_held(logits, static_cast<const int16_t*>(labels), dlogits, nll, rows, cols, inv_rows, mean_out);
+        else if (label_itemsize == 4) launch_cross_entropy_held(logits, static_cast<const int32_t*>(labels), dlogits, nll, rows, cols, inv_rows, mean_out);
+        else                          launch_cross_entropy_held(logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows, mean_out);
+        *mean_done = mean_out != nullptr;
         LG_CHECK_LAUNCH();
         return LG_OK;
     }
@@ -585,6 +618,27 @@ extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int
         hipLaunchKernelGGL(cross_entropy_rows<int64_t>, grid, block, 0, s, logits, static_cast<const int64_t*>(labels), dlogits, nll, rows, cols, inv_rows, rt().status_dev);
     LG_CHECK_LAUNCH();
     return LG_OK;
+}
+
+extern "C" int lg_cross_entropy_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                                    int64_t rows, int64_t cols) {
+    bool done = false;
+    return cross_entropy_impl(logits, labels, label_itemsize, dlogits, nll, rows, cols, nullptr, &done);
+}
+
+extern "C" int lg_cross_entropy_mean_f32(const float* logits, const void* labels, int label_itemsize, float* dlogits, float* nll,
+                                         float* mean, int64_t rows, int64_t cols) {
+    LG_ARG(mean != nullptr && rows >= 1, "lg_cross_entropy_mean_f32: needs rows >= 1 and a place for the mean");
+    bool done = false;
+    int rc = cross_entropy_impl(logits, labels, label_itemsize, dlogits, nll, rows, cols, mean, &done);
+    if (rc != LG_OK || done) return rc;
+    // the kernels for narrow / very wide rows leave the mean to the generic reduction: sum, then * (1 / rows)
+    const int64_t shape[1] = {rows}, strides[1] = {1};
+    rc = lg_reduce(LG_RED_SUM, 1, shape, nll, strides, 1u, mean);
+    if (rc != LG_OK) return rc;
+    const int64_t none[1] = {1};
+    return lg_ew(LG_EW_MUL, 0, none, mean, none, nullptr, nullptr, mean, none, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 float(1.0 / double(rows)));                       // mean = mean * (1 / rows): the scalar is operand b
 }
 
 namespace lg {
@@ -650,7 +704,7 @@ extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, f
     if (queue) {
         bool clash = false;
         for (int i = 0; i < S.count; ++i) clash = clash || S.grp.e[i].dw == dw || S.grp.e[i].db == db;
-        if (clash || S.count == kLnGroupMax || S.tickets + blocks_x > rt().n_gemm_tickets / 2) {
+        if (clash || S.count == kLnGroupMax || S.tickets + blocks_x > rt().n_gemm_tickets / 2 - 1) {      // (the very last slot: the loss kernel's)
             const int rc = ln_group_flush_pending();
             if (rc != LG_OK) return rc;
         }

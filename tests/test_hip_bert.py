@@ -149,6 +149,26 @@ def test_embedding_gather_and_scatter_add(hip):
         (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
         (ct[CpuTensor.from_numpy(ids, requires_grad=False)] * CpuTensor.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
         np.testing.assert_allclose(tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # the scatter-add for one batch of ids (<= 4096): a table row that receives at most 32 ids is summed in position order like
+    # np.add.at - numpy's BITS; hotter rows (a padding id: chunks of 32, combined atomically) and larger batches are not ordered
+    from lightgrad_amd.autograd.hip import ops as H
+    for n_ids, hot in [(1500, False), (4096, False), (1500, True), (5000, False)]:
+        ids = rng.permutation(20000)[:n_ids].astype(np.int32) % 4000          # a few repeats
+        ids[10:16] = ids[3]                                                    # one id seven times: still ordered
+        if hot:
+            ids[100::3] = 17                                                   # hundreds of times: the atomic path
+        g = rng.uniform(-1, 1, (n_ids, 12)).astype(np.float32)
+        start = rng.uniform(-1, 1, (4000, 12)).astype(np.float32)
+        want = start.copy()
+        np.add.at(want, ids, g)
+        into = hip.from_numpy(start, requires_grad=False)
+        H._scatter_add_rows((4000, 12), hip.from_numpy(ids, requires_grad=False), hip.from_numpy(g, requires_grad=False), into=into)
+        got = into.numpy()
+        if n_ids <= 4096:
+            cool = np.ones(4000, bool)
+            cool[17] = not hot
+            np.testing.assert_array_equal(got[cool], want[cool], err_msg=str((n_ids, hot)))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=str((n_ids, hot)))
 
 
 def test_parameter_gradients_accumulate_in_place(hip):

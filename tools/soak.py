@@ -127,7 +127,7 @@ while time.perf_counter() - t0 < budget:
 after = pool()
 scale = float(np.abs(reference).max())
 print("tiny-BERT replays: %d in %.1f s (%.3f ms each), loss %.6f every time; largest gradient difference to the first replay %.3g "
-      "(largest gradient %.3g; the embedding tables are accumulated with float atomics); pool in use %d -> %d B"
+      "(largest gradient %.3g; embedding rows that receive more than 32 ids are combined with float atomics); pool in use %d -> %d B"
       % (n, time.perf_counter() - t0, 1e3 * (time.perf_counter() - t0) / n, ref_loss, worst, scale, before[0], after[0]))
 assert worst <= 1e-5 * scale and after[0] == before[0]
 print("soak ok")

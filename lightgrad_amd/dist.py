@@ -97,6 +97,33 @@ class GlooCommunicator(Communicator):
         self._dist.barrier()
 
 
+class HostStagedCommunicator(GlooCommunicator):
+    """GPU ranks whose collectives travel through host memory: device -> host copy, gloo, host -> device copy.
+
+    Not a fast path and not used by bench.py - RCCL is (RcclCommunicator).  It exists so that everything ABOVE the collective
+    (flat HipTensor bucket, gradient hooks, the fused multi-tensor optimizer with grad_scale = 1 / world, replica identity) can
+    be exercised with world_size > 1 on a box with ONE GPU, where RCCL refuses a second rank on the same device
+    (tests/test_hip_dist.py).  Every call synchronises the stream; nothing here can be captured into a hipGraph."""
+
+    def _staged(self, flat, reduce):
+        assert not isinstance(flat, CpuTensor), "HostStagedCommunicator is for device tensors; CPU ranks use GlooCommunicator"
+        assert flat.is_contiguous(), "collectives run on dense buckets"
+        import torch
+        host = np.ascontiguousarray(flat.numpy())                 # device -> host (synchronises)
+        reduce(torch.from_numpy(host))
+        flat.upload_(host)                                        # host -> device, ordered on the stream
+        return flat
+
+    def allreduce_sum_(self, flat, forked=False):
+        return self._staged(flat, lambda t: self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM))
+
+    def allreduce_max_(self, flat):
+        return self._staged(flat, lambda t: self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX))
+
+    def broadcast_(self, flat, root=0):
+        return self._staged(flat, lambda t: self._dist.broadcast(t, src=root))
+
+
 def _exchange_unique_id(rank, make_id, path, timeout=300.0):
     """rank 0 writes the 128-byte RCCL id to `path` atomically, the others poll for it (single node)"""
     if rank == 0:

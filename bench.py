@@ -55,6 +55,10 @@ def parse():
                          "with the input-gradient GEMM (no host call per step); graph-inline = inside the captured step on the "
                          "compute stream (no branch, no overlap); eager = forward+backward replay from a graph, all-reduce and "
                          "optimizer are host calls; auto = time a short run of each and keep the fastest (all ranks agree)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 on a box with ONE GPU: every rank binds device 0 and the collectives are staged through the host "
+                         "(gloo) - a rehearsal of the multi-rank code of this script and of DataParallel, NOT a measurement "
+                         "(RCCL refuses a second rank on a device); the metric name says so")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="training steps recorded per hipGraph (each one complete: forward, backward, exchange, update); a replay "
                          "boundary costs ~8 us of idle GPU, so several steps per graph amortise it.  1 = one step per replay")
@@ -173,10 +177,20 @@ def gpu_rank(args, rank, world):
     from lightgrad_amd.autograd.hip import HipDevice, HipGraph, lib as L
     from lightgrad_amd.dist import RcclCommunicator, SingleProcess, DataParallel
 
+    if args.rehearse_on_one_gpu:
+        os.environ["LIGHTGRAD_HIP_DEVICE"] = "0"     # every rank on the one GPU
     lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
     info = HipDevice.info()
     multi = world > 1 or args.force_comm
-    comm = RcclCommunicator(rank, world) if multi else SingleProcess()
+    if args.rehearse_on_one_gpu and world > 1:
+        import torch.distributed as tdist
+        from lightgrad_amd.dist import HostStagedCommunicator, _c_stdout_to_stderr
+        with _c_stdout_to_stderr():                  # gloo prints a banner on stdout; stdout carries the one JSON line
+            tdist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ["MASTER_PORT"]),
+                                     rank=rank, world_size=world)
+        comm = HostStagedCommunicator()
+    else:
+        comm = RcclCommunicator(rank, world) if multi else SingleProcess()
     # rocprofv3 (ROCm 7.2) faults in its HSA queue interceptor when a hipGraph's packet batch crosses the end of the
     # 16384-packet AQL ring (profiles/README.md, r2): keep the number of replayed graph nodes small when it is attached
     under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
@@ -413,7 +427,7 @@ def gpu_rank(args, rank, world):
     w0, x_np, onehot_np = R["w0"], R["x_np"], R["onehot_np"]
 
     ranks_info = {"world_size": world, "communicator": type(comm).__name__,
-                  "communicator_ranks": comm.ranks_seen() if multi else 1,          # lg_comm_rank: what RCCL itself reports
+                  "communicator_ranks": (comm.ranks_seen() if hasattr(comm, "ranks_seen") else comm.world_size) if multi else 1,   # lg_comm_rank: what RCCL itself reports
                   "per_rank_steps_per_sec": [round(v, 2) for v in per_rank],
                   "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else
                               ("torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"),
@@ -427,7 +441,8 @@ def gpu_rank(args, rank, world):
                   "in_graph_exchange_fallback": fallback_reason}
 
     out = {
-        "metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",
+        "metric": ("REHEARSAL_ranks_share_one_gpu_host_staged_collectives__" if args.rehearse_on_one_gpu else "") +
+                  "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(steps_per_s, 2), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",

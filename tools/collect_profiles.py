@@ -14,6 +14,8 @@ for extra in ("hbm_bench", "mlp_gemm_bench", "head_bench", "gemm_timeline", "pmc
               "step_gap_eight_steps_per_graph", "wrap_summary", "bert_step_trace", "bert_bench", "bert_gemm_bench", "ce_bench", "graph_branch_probe", "soak", "dist_two_ranks_one_gpu"):
     if os.path.exists(os.path.join(src, extra + ".txt")):
         shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
+if os.path.exists(os.path.join(src, "bench_rehearsal_two_ranks_one_gpu.json")):
+    shutil.copy(os.path.join(src, "bench_rehearsal_two_ranks_one_gpu.json"), os.path.join(dst, "bench_rehearsal_two_ranks_one_gpu_%s.json" % tag))
 pmc = {}
 for kind in ("fetch", "write"):
     f = newest("%s/%s/*/*_counter_collection.csv" % (src, kind))

@@ -29,6 +29,7 @@ python tools/bert_bench.py --trace $out/berttrace/*/*_kernel_trace.csv > $out/be
 step bertbench 200 "python tools/bert_bench.py > $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 (weight gradients launched where the tape makes them, dW and dx paired)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 (weight gradients on a second stream: parallel branches of the hipGraph)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1"; cat $out/bert_bench.txt
 step bertgemm 100 "python tools/bert_gemm_bench.py > $out/bert_gemm_bench.txt 2>&1"; cat $out/bert_gemm_bench.txt
 step cebench 100 "python tools/ce_bench.py > $out/ce_bench.txt 2>&1; LG_CE_HELD=0 python tools/ce_bench.py >> $out/ce_bench.txt 2>&1"; cat $out/ce_bench.txt
+step rehearse 400 "python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-cpu-baseline > $out/bench_rehearsal_two_ranks_one_gpu.json 2> $out/bench_rehearsal.err"; tail -c 300 $out/bench_rehearsal_two_ranks_one_gpu.json
 step dist2 300 "LIGHTGRAD_MULTIPROC_GPU_TESTS=1 python -m pytest tests/test_hip_dist.py -m gpu -q > $out/dist_two_ranks_one_gpu.txt 2>&1"; tail -2 $out/dist_two_ranks_one_gpu.txt
 step soak 200 "python tools/soak.py 20 > $out/soak.txt 2>&1"; cat $out/soak.txt
 step branchprobe 100 "python tools/graph_branch_probe.py > $out/graph_branch_probe.txt 2>&1"; cat $out/graph_branch_probe.txt

@@ -261,3 +261,20 @@ def test_constants_of_the_tape_do_not_grow_nodes():
     assert c.ctx is None and not c.requires_grad
     c.backward(allow_fill=True)                                    # nothing to do, like backward on a leaf
     assert c.grad is None
+
+
+def test_linear_residual_argument_is_the_plain_sum():
+    """nn.Linear.forward(x, residual=r) (extension used by examples/bert.py) == Linear(x) + r, values and gradients, bit for bit"""
+    rng = np.random.RandomState(12)
+    x, r, g = (rng.uniform(-1, 1, (3, 5, 8)).astype(np.float32) for _ in range(3))
+    lin = light.nn.Linear(8, 8)
+    results = []
+    for fused in (True, False):
+        for p in lin.parameters():
+            p.zero_grad()
+        tx, tr = CpuTensor.from_numpy(x), CpuTensor.from_numpy(r)
+        y = lin(tx, residual=tr) if fused else lin(tx) + tr
+        (y * CpuTensor.from_numpy(g, requires_grad=False)).backward(allow_fill=True)
+        results.append([y.numpy().copy(), tx.grad.numpy().copy(), tr.grad.numpy().copy()] + [p.grad.numpy().copy() for p in lin.parameters()])
+    for a, b in zip(*results):
+        np.testing.assert_array_equal(a, b)

@@ -339,8 +339,9 @@ int lg_gemm_pair_end(void);
  * 64 x 64) are prepared and QUEUED instead of launched (up to 14), and so are lg_layernorm_param_grads_f32 calls (up to 8);
  * anything else inside the bracket runs as usual.  The queue outlives the bracket: lg_gemm_group_flush launches it - one
  * GEMM kernel, one LayerNorm kernel.  It is also launched when full, when a call writes where a queued one writes, and
- * before lg_sync, lg_memcpy_d2h, lg_graph_launch and the end of a capture.  Results are those of the immediate launches;
- * only WHEN they are computed changes: the caller must keep the queued calls' operands alive and unchanged and must not read
+ * before lg_sync, lg_memcpy_d2h, lg_graph_launch and the end of a capture.  Values are those of the immediate launches up to
+ * rounding (a queued product always takes the 64 x 64 tile; launched at once it might split K differently); what changes is
+ * WHEN they are computed: the caller must keep the queued calls' operands alive and unchanged and must not read
  * their outputs until the flush.  Made for the backward pass of a deep network: each Linear's weight gradient is a small
  * product with a long K (12 us alone, most of it launch, prologue and split-K hand-off on a handful of workgroups) that
  * nothing but the optimizer waits for; together they cost what the largest costs.  New design, no reference analog. */

@@ -242,3 +242,67 @@ def test_attention_shaped_products_forward_backward(hip):
         grads[cls] = [ctx.numpy()] + [t.grad.numpy() for t in (q, k, v)]
     for got, ref, name in zip(grads[hip], grads[CpuTensor], ["ctx", "dq", "dk", "dv"]):
         assert rel_err(got, ref.astype(np.float64)) <= 2e-5, name
+
+
+def test_group_queue_edge_cases_through_the_c_abi(hip):
+    """lg_gemm_group_*: queued weight-gradient products give the values of immediate launches - more products than the queue holds
+    (a flush in the middle), two products onto the SAME output (the second flushes the first, then accumulates), a product with the
+    row-sum column, one too large to be queued, LayerNorm parameter gradients riding along, a product of another layout passing
+    through a bracket untouched, and a flush forced by lg_sync"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(77)
+
+    def dev(a):
+        return hip.from_numpy(np.ascontiguousarray(a, np.float32), requires_grad=False)
+
+    def wgrad(g, x, out, accumulate=0, rowsum=None):
+        m, n, k = g.shape[1], x.shape[1], g.shape[0]
+        if rowsum is None:
+            L.check(lib.lg_gemm_f32(1, 0, m, n, k, g.ptr, m, 0, x.ptr, n, 0, out.ptr, n, 0, 1, accumulate))
+        else:
+            L.check(lib.lg_gemm_rowsum_f32(1, 0, m, n, k, g.ptr, m, x.ptr, n, out.ptr, n, accumulate, rowsum.ptr, 0))
+
+    shapes = [(256, 96, 80), (512, 128, 128), (100, 33, 50), (1024, 64, 200)] * 5                      # 20 products: > 14
+    gs = [dev(rng.uniform(-1, 1, (k, m))) for k, m, n in shapes]
+    xs = [dev(rng.uniform(-1, 1, (k, n))) for k, m, n in shapes]
+    want = [hip.empty((m, n), requires_grad=False) for k, m, n in shapes]
+    for g, x, o in zip(gs, xs, want):
+        wgrad(g, x, o)
+    got = [hip.empty((m, n), requires_grad=False) for k, m, n in shapes]
+    L.check(lib.lg_gemm_group_begin())
+    for g, x, o in zip(gs, xs, got):
+        wgrad(g, x, o)
+    L.check(lib.lg_gemm_group_end())
+    L.check(lib.lg_gemm_group_flush())
+    for a, b in zip(got, want):            # (a queued product always takes the 64x64 tile, an immediate one may split K differently)
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-5 * np.abs(b.numpy()).max())
+    # same output twice (+ accumulate), a row-sum product, an oversized product, a LayerNorm entry, a foreign layout - one bracket
+    g1, x1, g2, x2 = gs[1], xs[1], dev(rng.uniform(-1, 1, (512, 128))), dev(rng.uniform(-1, 1, (512, 128)))
+    big_g, big_x = dev(rng.uniform(-1, 1, (64, 70000))), dev(rng.uniform(-1, 1, (64, 64)))          # 1094 x 1 tiles > 1024: immediate
+    ln_g, ln_xhat = dev(rng.uniform(-1, 1, (300, 96))), dev(rng.uniform(-1, 1, (300, 96)))
+    a_nn, b_nn = dev(rng.uniform(-1, 1, (70, 40))), dev(rng.uniform(-1, 1, (40, 90)))
+
+    def run(queued):
+        out = hip.empty((128, 128), requires_grad=False)
+        rs_out, rs = hip.empty((128, 128), requires_grad=False), hip.empty((128,), requires_grad=False)
+        big_out = hip.empty((70000, 64), requires_grad=False)
+        dw, db = hip.empty((96,), requires_grad=False), hip.empty((96,), requires_grad=False)
+        nn_out = hip.empty((70, 90), requires_grad=False)
+        if queued:
+            L.check(lib.lg_gemm_group_begin())
+        wgrad(g1, x1, out)                                       # out = g1^T x1
+        wgrad(g2, x2, out, accumulate=1)                         # out += g2^T x2: must not share a launch with the first
+        wgrad(g1, x1, rs_out, rowsum=rs)
+        wgrad(big_g, big_x, big_out)
+        L.check(lib.lg_layernorm_param_grads_f32(ln_g.ptr, ln_xhat.ptr, dw.ptr, db.ptr, 300, 96, 0, 0))
+        L.check(lib.lg_gemm_f32(0, 0, 70, 90, 40, a_nn.ptr, 40, 0, b_nn.ptr, 90, 0, nn_out.ptr, 90, 0, 1, 0))
+        if queued:
+            L.check(lib.lg_gemm_group_end())
+            L.check(lib.lg_sync())                               # flushes what is still queued
+        return [t.numpy() for t in (out, rs_out, rs, big_out, dw, db, nn_out)]
+
+    for a, b in zip(run(True), run(False)):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * np.abs(b).max())
+    ref = g1.numpy().astype(np.float64).T @ x1.numpy() + g2.numpy().astype(np.float64).T @ x2.numpy()
+    np.testing.assert_allclose(run(True)[0], ref, rtol=1e-5, atol=1e-4)

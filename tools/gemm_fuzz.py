@@ -1,6 +1,6 @@
 """Randomised parity sweep of the SGEMM entry points against float64 numpy: shapes 1..700 (plus a few large ones), all
 four operand layouts, misaligned views (row / column offsets inside a bigger buffer), accumulate, bias, row sums, relu on
-either operand, two-level batches.  Run on the GPU box:  python tools/gemm_fuzz.py [seconds=60] [seed=0]"""
+either operand, two-level batches, the addend epilogue, paired and queued (group) launches, stride-permuted output layouts.  Run on the GPU box:  python tools/gemm_fuzz.py [seconds=60] [seed=0]"""
 import os
 import sys
 import time
@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightgrad_amd import HipTensor                          # noqa: E402
 from lightgrad_amd.autograd.hip import ops as H              # noqa: E402
+from lightgrad_amd.autograd.hip import lib as L              # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -47,7 +48,7 @@ while time.time() - t0 < budget:
         M, N, K = [int(v) if rng.rand() < 0.5 else int(rng.choice([1, 2, 3, 4, 5, 8, 10, 16, 31, 32, 33, 63, 64, 65])) for v in (M, N, K)]
     a, b = rng.uniform(-1, 1, (M, K)).astype(np.float32), rng.uniform(-1, 1, (K, N)).astype(np.float32)
     ta, tb = view(a, rng.rand() < 0.5), view(b, rng.rand() < 0.5)
-    mode = rng.randint(0, 6)
+    mode = rng.randint(0, 10)
     a64, b64 = a.astype(np.float64), b.astype(np.float64)
     tag = "M=%d N=%d K=%d mode=%d" % (M, N, K, mode)
     if mode == 0:
@@ -73,6 +74,57 @@ while time.time() - t0 < budget:
             bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
             out, _ = H._gemm_fused(ta, tb, relu_a=ra, relu_b=rb, bias=HipTensor.from_numpy(bias, requires_grad=False))
             e = rel(out.numpy(), a_eff @ b_eff + bias)
+    elif mode == 6:                                   # bias + addend epilogue: (a @ b + bias) + r
+        bias = rng.uniform(-1, 1, (N,)).astype(np.float32) if rng.rand() < 0.5 else None
+        r = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        out = H._gemm(ta, tb, bias=None if bias is None else HipTensor.from_numpy(bias, requires_grad=False),
+                      addend=HipTensor.from_numpy(r, requires_grad=False))
+        e = rel(out.numpy(), a64 @ b64 + (0 if bias is None else bias) + r)
+    elif mode == 7:                                   # two products in one launch (lg_gemm_pair_*): whatever qualifies is paired
+        g_ = rng.uniform(-1, 1, (K, M)).astype(np.float32)                       # dW = g^T @ x  and  dx = g @ w
+        x_, w_ = rng.uniform(-1, 1, (K, N)).astype(np.float32), rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        tg, tx, tw = (HipTensor.from_numpy(v, requires_grad=False) for v in (g_, x_, w_))
+        L.check(L.lib().lg_gemm_pair_begin())
+        dw = H._gemm(H._swap_last(tg), tx)
+        dx = H._gemm(tg, tw)
+        L.check(L.lib().lg_gemm_pair_end())
+        e = max(rel(dw.numpy(), g_.astype(np.float64).T @ x_), rel(dx.numpy(), g_.astype(np.float64) @ w_))
+        tag += " (pair)"
+    elif mode == 8:                                   # weight-gradient products queued (lg_gemm_group_*) and flushed together
+        cases = []
+        L.check(L.lib().lg_gemm_group_begin())
+        for _ in range(int(rng.randint(1, 6))):
+            kk, mm, nn = int(rng.randint(1, 400)), int(rng.randint(1, 300)), int(rng.randint(1, 300))
+            g_, x_ = rng.uniform(-1, 1, (kk, mm)).astype(np.float32), rng.uniform(-1, 1, (kk, nn)).astype(np.float32)
+            tg, tx = HipTensor.from_numpy(g_, requires_grad=False), HipTensor.from_numpy(x_, requires_grad=False)
+            if rng.rand() < 0.5:
+                out, rs = H._gemm_rowsum(H._swap_last(tg), tx)
+            else:
+                out, rs = H._gemm(H._swap_last(tg), tx), None
+            cases.append((g_, x_, out, rs, tg, tx))
+        L.check(L.lib().lg_gemm_group_end())
+        L.check(L.lib().lg_gemm_group_flush())
+        e = 0.0
+        for g_, x_, out, rs, _, _ in cases:
+            e = max(e, rel(out.numpy(), g_.astype(np.float64).T @ x_))
+            if rs is not None:
+                e = max(e, rs_err(rs.numpy(), g_.astype(np.float64).T))
+        tag = "group of %d" % len(cases)
+    elif mode == 9:                                   # batched product stored in a stride-permuted dense layout
+        bo, bi, s, d, s2 = (int(rng.randint(1, 4)), int(rng.randint(1, 4)), int(rng.randint(1, 70)), int(rng.randint(1, 40)), int(rng.randint(1, 70)))
+        pa, pb = rng.uniform(-1, 1, (bo, bi, s, d)).astype(np.float32), rng.uniform(-1, 1, (bo, bi, d, s2)).astype(np.float32)
+        shape = (bo, bi, s, s2)
+        perm = list(rng.permutation(4))                                           # memory order, outermost first
+        strides, run_ = [0] * 4, 1
+        for dim in reversed(perm):
+            strides[dim] = run_
+            run_ *= shape[dim]
+        if 1 not in (strides[-1], strides[-2]) and not (shape[-1] == 1 or shape[-2] == 1):
+            strides = None
+        out = H._gemm(HipTensor.from_numpy(pa, requires_grad=False), HipTensor.from_numpy(pb, requires_grad=False),
+                      out_strides=None if strides is None else tuple(strides))
+        e = rel(out.numpy(), pa.astype(np.float64) @ pb)
+        tag = "layout %s strides %s" % (shape, strides)
     else:                                             # two-level batch (attention layout), smaller extents
         bo, bi, s, d = int(rng.randint(1, 4)), int(rng.randint(1, 4)), int(rng.randint(1, 70)), int(rng.randint(1, 40))
         q, k = rng.uniform(-1, 1, (bo, s, bi, d)).astype(np.float32), rng.uniform(-1, 1, (bo, s, bi, d)).astype(np.float32)

@@ -578,12 +578,29 @@ class dot(Function):
         # each gradient in the memory layout of the operand it belongs to (a head-split view, a transposed matrix): the
         # transpose / reshape backward that follow are then views, not gathered copies
         same_batch = a._shape[:-2] == b._shape[:-2] == out_grad._shape[:-2]
-        if ga is None:
+
+        def grad_a():
             like = _layout_like(a) if same_batch else None
-            ga = _gemm(out_grad, _swap_last(b), out_strides=like) if like is not None else _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
-        if gb is None:
+            return _gemm(out_grad, _swap_last(b), out_strides=like) if like is not None else _gemm(out_grad, _swap_last(b), out_colmajor=_is_colmajor(a))
+
+        def grad_b():
             like = _layout_like(b) if same_batch else None
-            gb = _gemm(_swap_last(a), out_grad, out_strides=like) if like is not None else _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
+            return _gemm(_swap_last(a), out_grad, out_strides=like) if like is not None else _gemm(_swap_last(a), out_grad, out_colmajor=_is_colmajor(b))
+
+        if ga is None and gb is None and len(a._shape) > 2 and out_grad.numel() > 0:
+            # attention's two gradients per product (dS^T @ q with dS @ k;  probs^T @ dO with dO @ v^T): independent, small, and in
+            # the layouts the two-product launch takes - one launch instead of two (lg_gemm_pair_*; the M-contiguous-A product
+            # has to be offered first).  Whatever does not fit the pair is launched on its own, as without the bracket.
+            _l.check(_l.lib().lg_gemm_pair_begin())
+            try:
+                gb = grad_b()
+                ga = grad_a()
+            finally:
+                _l.check(_l.lib().lg_gemm_pair_end())
+        if ga is None:
+            ga = grad_a()
+        if gb is None:
+            gb = grad_b()
         return (None if ga is False else ga), (None if gb is False else gb)
 
 

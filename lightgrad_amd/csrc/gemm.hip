@@ -146,21 +146,21 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
 // of MFMAs); together their workgroups share the CUs and interleave (0.51 us per K-tile each when two are resident), and one
 // launch floor (3 us) disappears.  Layouts: the first product A^T-form (M-contiguous A, N-contiguous B), the second
 // K-contiguous A and N-contiguous B - what dense row-major g, x, W give.
-template <int PD>
+template <int PD, bool SECOND_BKC = false>
 __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, GemmArgs second) {
-    constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, false, 1>();
+    constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, SECOND_BKC, 1>();
     __shared__ __attribute__((aligned(16))) float lds[L1 > L2 ? L1 : L2];
     constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
-    constexpr bool VA = true, VB = true, BKC = false;
+    constexpr bool VA = true, VB = true;
 #define LG_TILE_OWNS_LDS 0
     if (int(blockIdx.x) < first.nwg) {
-        constexpr bool AKC = false;
+        constexpr bool AKC = false, BKC = false;
         const GemmArgs& g = first;
 #define LG_TILE_BID int(blockIdx.x)
 #include "gemm_tile_body.inc"
 #undef LG_TILE_BID
     } else {
-        constexpr bool AKC = true;
+        constexpr bool AKC = true, BKC = SECOND_BKC;
         const GemmArgs& g = second;
 #define LG_TILE_BID (int(blockIdx.x) - first.nwg)
 #include "gemm_tile_body.inc"
@@ -218,6 +218,7 @@ static void lg_debug_timeline_state(unsigned long long* buf, int nwg, int slices
 struct PairState {
     int      active = 0;       // 0: no bracket; 1: collecting; 2: bracket open but no longer collecting
     int      count = 0;
+    bool     second_bkc = false;     // layout of the second product's B: K-contiguous (g @ v^T of attention) or N-contiguous (g @ W)
     GemmArgs args[2];
 };
 static PairState& pair_state() { static PairState p; return p; }
@@ -226,6 +227,7 @@ static void pair_launch_single(const GemmArgs& g, int slot) {
     dim3 grid(g.nwg), block(256);
     constexpr int PD = kSmallTilePrefetch;
     if (slot == 0) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, false, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
+    else if (pair_state().second_bkc) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, true, true, true, PD, 1>), grid, block, 0, rt().stream, g);
     else           hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
 }
 
@@ -239,8 +241,12 @@ static int pair_flush(bool keep_collecting) {
             lg_debug_timeline_state(P.args[0].tl, P.args[0].nwg + P.args[1].nwg, P.args[0].k_slices * 100 + P.args[1].k_slices, P.args[0].nwg);
         }
 #endif
-        hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
-                           P.args[0], P.args[1]);
+        if (P.second_bkc)
+            hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch, true>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
+                               P.args[0], P.args[1]);
+        else
+            hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch, false>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
+                               P.args[0], P.args[1]);
     } else if (P.count == 1) {
         pair_launch_single(P.args[0], 0);
     }
@@ -256,10 +262,13 @@ static bool pair_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, in
     PairState& P = pair_state();
     if (P.active != 1) return false;
     const int slot = P.count;
-    const bool fits = slot < 2 && va && vb && batch == 1 && !bkc && (slot == 0 ? !akc : akc);
-    const int64_t first_tiles = slot == 1 ? int64_t(P.args[0].tiles_m) * P.args[0].tiles_n : 0;
-    if (!fits || first_tiles + int64_t(g.tiles_m) * g.tiles_n > rt().n_gemm_tickets) return false;
+    // first: M-contiguous A, N-contiguous B (g^T @ x, probs^T @ dO, dS^T @ q); second: K-contiguous A and either kind of B
+    // (g @ W, dS @ k; dO @ v^T).  Batched products (attention: one matrix per (batch, head)) pair like single ones.
+    const bool fits = slot < 2 && va && vb && batch >= 1 && (slot == 0 ? (!akc && !bkc) : akc);
+    const int64_t first_tiles = slot == 1 ? int64_t(P.args[0].tiles_m) * P.args[0].tiles_n * (P.args[0].nwg / (int64_t(P.args[0].tiles_m) * P.args[0].tiles_n * P.args[0].k_slices)) : 0;
+    if (!fits || first_tiles + int64_t(g.tiles_m) * g.tiles_n * batch > rt().n_gemm_tickets) return false;
     g.tickets = rt().gemm_tickets + first_tiles;           // the two products fold their K-slices with disjoint tickets
+    if (slot == 1) P.second_bkc = bkc;
     P.args[slot] = g;
     P.count = slot + 1;
     return true;

@@ -346,6 +346,10 @@ int lg_gemm_pair_end(void);
  * product with a long K (12 us alone, most of it launch, prologue and split-K hand-off on a handful of workgroups) that
  * nothing but the optimizer waits for; together they cost what the largest costs.  New design, no reference analog. */
 int lg_gemm_group_begin(void);
+/* out[c] (+)= sum over rows of in[r * ld + c]: the bias gradient of a Linear.  Inside a group bracket (one such job per
+ * flush) it is queued and computed by extra workgroups of the group's launch - memory-bound work next to MFMA-bound work;
+ * otherwise, or when the slot is taken, it is lg_reduce_acc at once.  Same caller obligations as for queued products. */
+int lg_gemm_group_colsum_f32(const float* in, int64_t ld, int64_t rows, int64_t cols, float* out, int accumulate);
 int lg_gemm_group_flush(void);
 int lg_gemm_group_end(void);
 

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "lg_gemm_pair_begin": (c_int, []),
     "lg_gemm_pair_end": (c_int, []),
     "lg_gemm_group_begin": (c_int, []),
+    "lg_gemm_group_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int]),
     "lg_gemm_group_flush": (c_int, []),
     "lg_gemm_group_end": (c_int, []),
     "lg_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double,

@@ -1214,7 +1214,12 @@ class linear(Function):
             else:
                 dw = _gemm(_swap_last(g2), x2)
         if want_db:
-            if acc_b is not None:
+            if acc_b is not None and GradGroup.issuing and g2.is_contiguous() and g2._dtype == _F32:
+                # queued with the weight gradients: the column sums are computed by extra workgroups of the group's launch
+                flush_lazy_readers(acc_b)
+                _l.check(_l.lib().lg_gemm_group_colsum_f32(g2.ptr, g2._shape[1], g2._shape[0], g2._shape[1], acc_b.ptr,
+                                                            0 if bias._consume_zero_pending() else 1))
+            elif acc_b is not None:
                 _reduce_into(acc_b, g2, (0,), overwrite=bias._consume_zero_pending())
             else:
                 db = _reduce(_l.RED_SUM, g2, (0,), False)

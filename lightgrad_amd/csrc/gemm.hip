@@ -176,8 +176,16 @@ __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, Ge
 constexpr int kGroupMax = 14;
 struct GemmGroup {
     GemmArgs p[kGroupMax];
-    int      first[kGroupMax + 1];      // first workgroup of each product; first[count] = all workgroups
+    int      first[kGroupMax + 1];      // first workgroup of each product (after the column-sum workgroups); first[count] = all of them
     int      count;
+    // one more job may ride along: column sums of a dense [rows, cols] matrix - the bias gradient of a Linear whose row-sum
+    // column would cost a whole extra tile column in its weight-gradient product (BERT's decoder: db = column sums of the
+    // (1024, 30522) logits gradient, 125 MB to read).  Memory-bound workgroups next to MFMA-bound ones: the 27 us of the
+    // separate reduction hide inside the group's launch.  cs_wgs workgroups of 64 columns each, at the FRONT of the grid.
+    const float* cs_in;
+    float*       cs_out;
+    int64_t      cs_rows, cs_cols, cs_ld;
+    int          cs_accumulate, cs_wgs;
 };
 
 static_assert(sizeof(GemmGroup) <= 4096, "the group travels as kernel arguments");
@@ -187,11 +195,34 @@ __global__ void __launch_bounds__(256) sgemm_group_wgrad(GemmGroup grp) {
     __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 32, false, false, 1>()];
     constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
     constexpr bool VA = true, VB = true, AKC = false, BKC = false;
+    if (int(blockIdx.x) < grp.cs_wgs) {
+        // column-sum role: 64 columns per workgroup, four row groups of 64 threads (row group q takes rows q, q + 4, ...), eight
+        // loads in flight per thread; the four partial sums are combined in a fixed order through LDS
+        const int q = threadIdx.x >> 6, cl = threadIdx.x & 63;
+        const int64_t col = int64_t(blockIdx.x) * 64 + cl;
+        const bool live = col < grp.cs_cols;
+        const float* in = grp.cs_in + (live ? col : 0);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int64_t r = q;
+        for (; r + 28 < grp.cs_rows; r += 32) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += in[(r + 4 * e) * grp.cs_ld];
+        }
+        for (; r < grp.cs_rows; r += 4) acc[0] += in[r * grp.cs_ld];
+        lds[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        __syncthreads();
+        if (q == 0 && live) {
+            const float v = (lds[cl] + lds[64 + cl]) + (lds[128 + cl] + lds[192 + cl]);
+            grp.cs_out[col] = grp.cs_accumulate ? grp.cs_out[col] + v : v;
+        }
+        return;
+    }
+    const int bid = int(blockIdx.x) - grp.cs_wgs;
     int which = 0;
-    while (which + 1 < grp.count && int(blockIdx.x) >= grp.first[which + 1]) ++which;      // uniform: scalar loads
+    while (which + 1 < grp.count && bid >= grp.first[which + 1]) ++which;      // uniform: scalar loads
     const GemmArgs& g = grp.p[which];
 #define LG_TILE_OWNS_LDS 0
-#define LG_TILE_BID (int(blockIdx.x) - grp.first[which])
+#define LG_TILE_BID (bid - grp.first[which])
 #include "gemm_tile_body.inc"
 #undef LG_TILE_BID
 #undef LG_TILE_OWNS_LDS
@@ -292,9 +323,16 @@ static GroupState& group_state() { static GroupState s; return s; }
 
 static int group_flush() {
     GroupState& G = group_state();
-    if (G.count == 0) return LG_OK;
+    if (G.count == 0) {
+        if (G.grp.cs_wgs > 0) {                       // column sums queued with nothing to ride on: the plain reduction
+            const int64_t shape[2] = {G.grp.cs_rows, G.grp.cs_cols}, strides[2] = {G.grp.cs_ld, 1};
+            G.grp.cs_wgs = 0;
+            return lg_reduce_acc(LG_RED_SUM, 2, shape, G.grp.cs_in, strides, 1u, G.grp.cs_out, G.grp.cs_accumulate);
+        }
+        return LG_OK;
+    }
     int rc = LG_OK;
-    if (G.count == 1) {
+    if (G.count == 1 && G.grp.cs_wgs == 0) {
         pair_launch_single(G.grp.p[0], 0);
     } else {
         // small products first: theirs are the long dependency chains (few workgroups, split-K hand-off and fold), a product
@@ -307,12 +345,13 @@ static int group_flush() {
         G.grp.first[0] = 0;
         for (int i = 0; i < G.count; ++i) { G.grp.p[i] = sorted[i]; G.grp.first[i + 1] = G.grp.first[i] + sorted[i].nwg; }
         G.grp.count = G.count;
-        hipLaunchKernelGGL((sgemm_group_wgrad<kSmallTilePrefetch>), dim3(G.grp.first[G.count]), dim3(256), 0, rt().stream, G.grp);
+        hipLaunchKernelGGL((sgemm_group_wgrad<kSmallTilePrefetch>), dim3(G.grp.cs_wgs + G.grp.first[G.count]), dim3(256), 0, rt().stream, G.grp);
     }
     for (int i = 0; i < G.count; ++i)
         if (G.grp.p[i].W) { const int r = lg_free(G.grp.p[i].W); if (r != LG_OK) rc = r; }     // stream-ordered
     G.count = 0;
     G.tiles = 0;
+    G.grp.cs_wgs = 0;
     return rc;
 }
 
@@ -702,4 +741,22 @@ extern "C" int lg_gemm_addend_f32(int transA, int transB, int64_t M, int64_t N, 
                                   const float* bias, const float* addend, int64_t ldadd) {
     LG_ARG(addend != nullptr, "lg_gemm_addend_f32: addend is NULL");
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, 0, bias, nullptr, 0, 1, 0, 0, 0, 0, 0, addend, ldadd);
+}
+
+extern "C" int lg_gemm_group_colsum_f32(const float* in, int64_t ld, int64_t rows, int64_t cols, float* out, int accumulate) {
+    LG_REQUIRE_INIT();
+    LG_ARG(in && out && rows >= 0 && cols >= 1 && ld >= cols, "lg_gemm_group_colsum_f32: bad arguments");
+    GroupState& G = lg::group_state();
+    const int64_t wgs = (cols + 63) / 64;
+    if (G.active == 1 && G.grp.cs_wgs == 0 && rows > 0 && wgs <= 65536 && !lg::pair_state().active) {
+        for (int i = 0; i < G.count; ++i)                    // never next to a queued product that writes the same buffer
+            if (G.grp.p[i].rowsum == out || G.grp.p[i].C == out) { const int rc = lg::group_flush(); if (rc != LG_OK) return rc; break; }
+        G.grp.cs_in = in; G.grp.cs_out = out;
+        G.grp.cs_rows = rows; G.grp.cs_cols = cols; G.grp.cs_ld = ld;
+        G.grp.cs_accumulate = accumulate;
+        G.grp.cs_wgs = int(wgs);
+        return LG_OK;
+    }
+    const int64_t shape[2] = {rows, cols}, strides[2] = {ld, 1};
+    return lg_reduce_acc(LG_RED_SUM, 2, shape, in, strides, 1u, out, accumulate);
 }

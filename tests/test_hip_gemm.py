@@ -282,6 +282,7 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
     big_g, big_x = dev(rng.uniform(-1, 1, (64, 70000))), dev(rng.uniform(-1, 1, (64, 64)))          # 1094 x 1 tiles > 1024: immediate
     ln_g, ln_xhat = dev(rng.uniform(-1, 1, (300, 96))), dev(rng.uniform(-1, 1, (300, 96)))
     a_nn, b_nn = dev(rng.uniform(-1, 1, (70, 40))), dev(rng.uniform(-1, 1, (40, 90)))
+    cs_in = dev(rng.uniform(-1, 1, (333, 1001)))
 
     def run(queued):
         out = hip.empty((128, 128), requires_grad=False)
@@ -289,6 +290,7 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
         big_out = hip.empty((70000, 64), requires_grad=False)
         dw, db = hip.empty((96,), requires_grad=False), hip.empty((96,), requires_grad=False)
         nn_out = hip.empty((70, 90), requires_grad=False)
+        cs_out, cs_acc = hip.empty((1001,), requires_grad=False), dev(np.ones(1001))
         if queued:
             L.check(lib.lg_gemm_group_begin())
         wgrad(g1, x1, out)                                       # out = g1^T x1
@@ -297,12 +299,16 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
         wgrad(big_g, big_x, big_out)
         L.check(lib.lg_layernorm_param_grads_f32(ln_g.ptr, ln_xhat.ptr, dw.ptr, db.ptr, 300, 96, 0, 0))
         L.check(lib.lg_gemm_f32(0, 0, 70, 90, 40, a_nn.ptr, 40, 0, b_nn.ptr, 90, 0, nn_out.ptr, 90, 0, 1, 0))
+        L.check(lib.lg_gemm_group_colsum_f32(cs_in.ptr, 1001, 333, 1001, cs_out.ptr, 0))      # rides in the group's launch
+        L.check(lib.lg_gemm_group_colsum_f32(cs_in.ptr, 1001, 333, 1001, cs_acc.ptr, 1))      # the slot is taken: computed at once
         if queued:
             L.check(lib.lg_gemm_group_end())
             L.check(lib.lg_sync())                               # flushes what is still queued
-        return [t.numpy() for t in (out, rs_out, rs, big_out, dw, db, nn_out)]
+        return [t.numpy() for t in (out, rs_out, rs, big_out, dw, db, nn_out, cs_out, cs_acc)]
 
     for a, b in zip(run(True), run(False)):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * np.abs(b).max())
+    np.testing.assert_allclose(run(True)[7], cs_in.numpy().astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(run(True)[8], 1 + cs_in.numpy().astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
     ref = g1.numpy().astype(np.float64).T @ x1.numpy() + g2.numpy().astype(np.float64).T @ x2.numpy()
     np.testing.assert_allclose(run(True)[0], ref, rtol=1e-5, atol=1e-4)

@@ -909,7 +909,11 @@ class getitem(Function):
             if acc is not None and acc.is_contiguous() and acc._dtype == _F32:
                 if table._consume_zero_pending():
                     acc.fill(0)
-                if SideStream.usable_for(table):
+                if GradGroup.usable_for(table) and idx.numel() <= 4096:
+                    ids_c, g_c = idx.contiguous(), out_grad.contiguous()        # (copies, if any, happen now, on the main chain)
+                    with GradGroup.issue(reads=(ids_c, g_c), writes=(acc,)):    # queued: leaves with the LayerNorm gradients
+                        _scatter_add_rows(shape, ids_c, g_c, into=acc)
+                elif SideStream.usable_for(table):
                     with SideStream.bracket(reads=(idx, out_grad), writes=(acc,)):
                         _scatter_add_rows(shape, idx, out_grad, into=acc)
                 else:

@@ -495,13 +495,12 @@ __global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict_
 // row cost 32 atomics per element instead of 1024 (tools/scatter_bench.py: 28.4 -> 14.5 us; ids without repeats 6 us either way).
 constexpr int kChunk = 32;
 template <typename IdT>
-__global__ void __launch_bounds__(256) scatter_add_rows_chunked(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
-                                                                float* __restrict__ grad_table, int64_t n_ids, int64_t row_len,
-                                                                int64_t table_rows, int* status) {
+__device__ __forceinline__ void scatter_add_rows_chunked_body(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
+                                                              float* __restrict__ grad_table, int64_t n_ids, int64_t row_len,
+                                                              int64_t table_rows, int* status, int64_t i) {
     __shared__ int before_total, same_total, found;
     __shared__ int wave_matches[4];
     __shared__ int later[kChunk];                    // the positions of this chunk behind the leader, ascending
-    const int64_t i = blockIdx.x;
     const int tid = threadIdx.x;
     int64_t mine = int64_t(ids[i]);
     if (mine < 0) mine += table_rows;
@@ -552,9 +551,86 @@ __global__ void __launch_bounds__(256) scatter_add_rows_chunked(const float* __r
     }
 }
 
+template <typename IdT>
+__global__ void __launch_bounds__(256) scatter_add_rows_chunked(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
+                                                                float* __restrict__ grad_table, int64_t n_ids, int64_t row_len,
+                                                                int64_t table_rows, int* status) {
+    scatter_add_rows_chunked_body<IdT>(grad_out, ids, grad_table, n_ids, row_len, table_rows, status, blockIdx.x);
+}
+
+// embedding gradients queued next to the LayerNorm parameter gradients (lg_gemm_group_*): they leave in the same launch
+constexpr int kScatterGroupMax = 4;
+struct ScatterJob {
+    const float* grad_out;
+    const void*  ids;
+    float*       table;
+    int64_t      n_ids, row_len, table_rows;
+    int          id_itemsize;
+};
+struct TailGroup {
+    LnParamGradsGroup ln;
+    ScatterJob        sc[kScatterGroupMax];
+    int               n_scatter;
+    int*              status;
+};
+
+__global__ void __launch_bounds__(256) param_grads_tail_group(TailGroup grp) {
+    const int z = int(blockIdx.z);
+    if (z < grp.ln.count) {
+        const LnParamGrads& a = grp.ln.e[z];
+        if (int(blockIdx.x) >= a.blocks_x || int(blockIdx.y) >= a.splits) return;      // this entry's own grid is smaller
+        layernorm_param_grads_body(a, int(blockIdx.x), blockIdx.y);
+        return;
+    }
+    const ScatterJob& j = grp.sc[z - grp.ln.count];
+    const int64_t i = int64_t(blockIdx.y) * gridDim.x + blockIdx.x;                     // one workgroup per id position
+    if (i >= j.n_ids) return;
+    if (j.id_itemsize == 4)
+        scatter_add_rows_chunked_body<int32_t>(j.grad_out, static_cast<const int32_t*>(j.ids), j.table, j.n_ids, j.row_len, j.table_rows, grp.status, i);
+    else
+        scatter_add_rows_chunked_body<int64_t>(j.grad_out, static_cast<const int64_t*>(j.ids), j.table, j.n_ids, j.row_len, j.table_rows, grp.status, i);
+}
+
 }  // namespace lg
 
 using namespace lg;
+
+namespace lg {
+struct LnGroupState {
+    int        count = 0;          // LayerNorm entries queued
+    int        n_scatter = 0;      // embedding scatter-adds queued
+    TailGroup  grp;
+    int64_t    tickets = 0;
+};
+static LnGroupState& ln_group() { static LnGroupState s; return s; }
+
+int ln_group_flush_pending() {
+    LnGroupState& S = ln_group();
+    if (S.count == 0 && S.n_scatter == 0) return LG_OK;
+    int rc = LG_OK;
+    if (S.count == 1 && S.n_scatter == 0) {
+        const LnParamGrads& a = S.grp.ln.e[0];
+        hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(a.blocks_x), unsigned(a.splits)), dim3(256), 0, rt().stream, a);
+    } else {
+        // grid: x * y workgroups per entry - enough for the widest LayerNorm entry (blocks_x by splits) and for one workgroup per
+        // id position of the longest scatter job; z = entry
+        int64_t bx = 1, sp = 1, ids = 0;
+        for (int i = 0; i < S.count; ++i) { bx = S.grp.ln.e[i].blocks_x > bx ? S.grp.ln.e[i].blocks_x : bx; sp = S.grp.ln.e[i].splits > sp ? S.grp.ln.e[i].splits : sp; }
+        for (int i = 0; i < S.n_scatter; ++i) ids = S.grp.sc[i].n_ids > ids ? S.grp.sc[i].n_ids : ids;
+        if (bx * sp < ids) bx = (ids + sp - 1) / sp;
+        S.grp.ln.count = S.count;
+        S.grp.n_scatter = S.n_scatter;
+        S.grp.status = rt().status_dev;
+        hipLaunchKernelGGL(param_grads_tail_group, dim3(unsigned(bx), unsigned(sp), unsigned(S.count + S.n_scatter)), dim3(256), 0, rt().stream, S.grp);
+    }
+    for (int i = 0; i < S.count; ++i)
+        if (S.grp.ln.e[i].partial) { const int r = lg_free(S.grp.ln.e[i].partial); if (r != LG_OK) rc = r; }       // stream-ordered
+    S.count = 0;
+    S.n_scatter = 0;
+    S.tickets = 0;
+    return rc;
+}
+}  // namespace lg
 
 extern "C" int lg_softmax_scaled_f32(const float* x, float* y, int64_t rows, int64_t cols, float scale) {
     LG_REQUIRE_INIT();
@@ -637,6 +713,21 @@ extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, i
     if (n_ids == 0 || row_len == 0) return LG_OK;
     LG_ARG(grad_out && ids && grad_table, "lg_scatter_add_rows_f32: NULL pointer");
     static const char* owner_env = getenv("LG_SCATTER_OWNER");        // experiments only: 0 = atomics for every size
+    if (n_ids <= 4096 && !(owner_env && atoi(owner_env) == 0) && gemm_group_is_open()) {
+        // inside a gradient group bracket (lg_gemm_group_begin): queued, and launched with the LayerNorm parameter gradients -
+        // the embedding tables' gradients are the last kernels of a backward pass, three launches of ~5 us of work each
+        LnGroupState& S = ln_group();
+        bool clash = false;
+        for (int i = 0; i < S.n_scatter; ++i) clash = clash || S.grp.sc[i].table == grad_table;        // tied tables: in call order
+        if (clash || S.n_scatter == kScatterGroupMax) {
+            const int rc = ln_group_flush_pending();
+            if (rc != LG_OK) return rc;
+        }
+        ScatterJob& j = S.grp.sc[S.n_scatter++];
+        j.grad_out = grad_out; j.ids = ids; j.table = grad_table;
+        j.n_ids = n_ids; j.row_len = row_len; j.table_rows = table_rows; j.id_itemsize = id_itemsize;
+        return LG_OK;
+    }
     if (n_ids <= 4096 && !(owner_env && atoi(owner_env) == 0)) {
         // the ids of one batch: chunks of 32 positions per id are summed in position order, few or no atomics (see the kernel)
         if (id_itemsize == 4)
@@ -718,35 +809,6 @@ extern "C" int lg_cross_entropy_mean_f32(const float* logits, const void* labels
                  float(1.0 / double(rows)));                       // mean = mean * (1 / rows): the scalar is operand b
 }
 
-namespace lg {
-struct LnGroupState {
-    int               count = 0;
-    LnParamGradsGroup grp;
-    int64_t           tickets = 0;
-};
-static LnGroupState& ln_group() { static LnGroupState s; return s; }
-
-int ln_group_flush_pending() {
-    LnGroupState& S = ln_group();
-    if (S.count == 0) return LG_OK;
-    int rc = LG_OK;
-    if (S.count == 1) {
-        const LnParamGrads& a = S.grp.e[0];
-        hipLaunchKernelGGL(layernorm_param_grads, dim3(unsigned(a.blocks_x), unsigned(a.splits)), dim3(256), 0, rt().stream, a);
-    } else {
-        int bx = 1, sp = 1;
-        for (int i = 0; i < S.count; ++i) { bx = S.grp.e[i].blocks_x > bx ? S.grp.e[i].blocks_x : bx; sp = S.grp.e[i].splits > sp ? S.grp.e[i].splits : sp; }
-        S.grp.count = S.count;
-        hipLaunchKernelGGL(layernorm_param_grads_group, dim3(unsigned(bx), unsigned(sp), unsigned(S.count)), dim3(256), 0, rt().stream, S.grp);
-    }
-    for (int i = 0; i < S.count; ++i)
-        if (S.grp.e[i].partial) { const int r = lg_free(S.grp.e[i].partial); if (r != LG_OK) rc = r; }       // stream-ordered
-    S.count = 0;
-    S.tickets = 0;
-    return rc;
-}
-}  // namespace lg
-
 extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, float* dw, float* db, int64_t rows, int64_t cols,
                                             int dw_accumulate, int db_accumulate) {
     LG_REQUIRE_INIT();
@@ -780,14 +842,14 @@ extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, f
     const bool queue = gemm_group_is_open() && blocks_x <= 64 && rows > 0;
     if (queue) {
         bool clash = false;
-        for (int i = 0; i < S.count; ++i) clash = clash || S.grp.e[i].dw == dw || S.grp.e[i].db == db;
+        for (int i = 0; i < S.count; ++i) clash = clash || S.grp.ln.e[i].dw == dw || S.grp.ln.e[i].db == db;
         if (clash || S.count == kLnGroupMax || S.tickets + blocks_x > rt().n_gemm_tickets / 2 - 1) {      // (the very last slot: the loss kernel's)
             const int rc = ln_group_flush_pending();
             if (rc != LG_OK) return rc;
         }
         a.tickets = rt().gemm_tickets + rt().n_gemm_tickets / 2 + S.tickets;
         S.tickets += blocks_x;
-        S.grp.e[S.count++] = a;
+        S.grp.ln.e[S.count++] = a;
         return LG_OK;
     }
     a.tickets = rt().gemm_tickets + rt().n_gemm_tickets / 2;

@@ -283,6 +283,10 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
     ln_g, ln_xhat = dev(rng.uniform(-1, 1, (300, 96))), dev(rng.uniform(-1, 1, (300, 96)))
     a_nn, b_nn = dev(rng.uniform(-1, 1, (70, 40))), dev(rng.uniform(-1, 1, (40, 90)))
     cs_in = dev(rng.uniform(-1, 1, (333, 1001)))
+    sc_ids_np = rng.randint(0, 300, 700).astype(np.int32)
+    sc_ids_np[::5] = 11                                                       # a hot row: more than 32 positions
+    sc_ids = hip.from_numpy(sc_ids_np, requires_grad=False)
+    sc_g = dev(rng.uniform(-1, 1, (700, 12)))
 
     def run(queued):
         out = hip.empty((128, 128), requires_grad=False)
@@ -291,6 +295,7 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
         dw, db = hip.empty((96,), requires_grad=False), hip.empty((96,), requires_grad=False)
         nn_out = hip.empty((70, 90), requires_grad=False)
         cs_out, cs_acc = hip.empty((1001,), requires_grad=False), dev(np.ones(1001))
+        sc_table = dev(np.zeros((300, 12)))
         if queued:
             L.check(lib.lg_gemm_group_begin())
         wgrad(g1, x1, out)                                       # out = g1^T x1
@@ -299,15 +304,20 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
         wgrad(big_g, big_x, big_out)
         L.check(lib.lg_layernorm_param_grads_f32(ln_g.ptr, ln_xhat.ptr, dw.ptr, db.ptr, 300, 96, 0, 0))
         L.check(lib.lg_gemm_f32(0, 0, 70, 90, 40, a_nn.ptr, 40, 0, b_nn.ptr, 90, 0, nn_out.ptr, 90, 0, 1, 0))
+        L.check(lib.lg_scatter_add_rows_f32(sc_g.ptr, sc_ids.ptr, 4, sc_table.ptr, 700, 12, 300))          # queued with the LayerNorm entry
+        L.check(lib.lg_scatter_add_rows_f32(sc_g.ptr, sc_ids.ptr, 4, sc_table.ptr, 700, 12, 300))          # same table again: flush, then queue
         L.check(lib.lg_gemm_group_colsum_f32(cs_in.ptr, 1001, 333, 1001, cs_out.ptr, 0))      # rides in the group's launch
         L.check(lib.lg_gemm_group_colsum_f32(cs_in.ptr, 1001, 333, 1001, cs_acc.ptr, 1))      # the slot is taken: computed at once
         if queued:
             L.check(lib.lg_gemm_group_end())
             L.check(lib.lg_sync())                               # flushes what is still queued
-        return [t.numpy() for t in (out, rs_out, rs, big_out, dw, db, nn_out, cs_out, cs_acc)]
+        return [t.numpy() for t in (out, rs_out, rs, big_out, dw, db, nn_out, cs_out, cs_acc, sc_table)]
 
     for a, b in zip(run(True), run(False)):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5 * np.abs(b).max())
+    want_table = np.zeros((300, 12), np.float64)
+    np.add.at(want_table, sc_ids_np, 2 * sc_g.numpy().astype(np.float64))
+    np.testing.assert_allclose(run(True)[9], want_table, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(run(True)[7], cs_in.numpy().astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(run(True)[8], 1 + cs_in.numpy().astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
     ref = g1.numpy().astype(np.float64).T @ x1.numpy() + g2.numpy().astype(np.float64).T @ x2.numpy()

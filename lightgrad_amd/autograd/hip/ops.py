@@ -91,6 +91,14 @@ def _alias(t):
     return HipTensor(t.data, t._shape, t._strides, t._offset, t._dtype, requires_grad=t.requires_grad)
 
 
+def _saved_output(y):
+    """what a node keeps of its OWN output for the backward (exp, tanh, softmax, pow, max: the gradient is a function of y): a
+    second tensor object on the same storage.  Saving y itself would close a reference cycle y -> ctx -> saved y, and the whole
+    tape behind it would live until python's cycle collector happens to run - measured on the eager tiny-BERT training loop: the
+    pool's reserved memory grew from 6.8 to 10.3 GB with 1 080 extra hipMalloc calls in 3 000 steps (tools/bert_train_soak.py)."""
+    return HipTensor(y.data, y._shape, y._strides, y._offset, y._dtype, requires_grad=False)
+
+
 """ Transformations """
 
 
@@ -236,7 +244,7 @@ class pow(Function):
     """ cpu/ops.py:96-105 """
     def forward(ctx, a, b):
         y = _pow_scalar(a, b) if _is_scalar(b) else _binary(_l.EW_POW, a, b)
-        ctx.save_for_backward(a, b, y)
+        ctx.save_for_backward(a, b, _saved_output(y))
         return y
 
     def backward(ctx, out_grad):
@@ -661,7 +669,7 @@ def _unary_op(name, fwd, bwd, save_output, cite):
     class Op(Function):
         def forward(ctx, t):
             y = _unary(fwd, t)
-            ctx.save_for_backward(y if save_output else t)
+            ctx.save_for_backward(_saved_output(y) if save_output else t)
             return y
 
         def backward(ctx, out_grad):
@@ -1019,7 +1027,7 @@ def _extremum(name, red_op, cite):
         def forward(ctx, x, axis=None, keepdims=False):
             axes = _norm_axes(len(x._shape), axis)
             val = _reduce(red_op, x, axes, True)
-            ctx.save_for_backward(x, val, axes, keepdims)
+            ctx.save_for_backward(x, _saved_output(val), axes, keepdims)
             if keepdims:
                 return val
             return HipTensor(val.data, tuple(s for i, s in enumerate(x._shape) if i not in axes), None, val._offset, val._dtype)
@@ -1438,7 +1446,7 @@ class softmax(Function):
         x, rows, cols = _rows_view(t)
         y = HipTensor.empty(x._shape)
         _l.check(_l.lib().lg_softmax_scaled_f32(x.ptr, y.ptr, rows, cols, float(scale)))
-        ctx.save_for_backward(y, perm, float(scale))
+        ctx.save_for_backward(_saved_output(y), perm, float(scale))
         if perm is not None:
             inv = [0] * nd
             for i, j in enumerate(perm):

@@ -328,3 +328,40 @@ def test_bert_training_steps_replayed_from_a_graph_match_the_eager_tape(hip):
         # (an Adam-type update normalises the gradient: where a gradient is rounding noise - the key projections, see the float64
         # test above - a last-bit difference from the atomically summed token-type embedding row moves a weight by a fraction of lr)
         np.testing.assert_allclose(q.numpy(), p.numpy(), rtol=2e-4, atol=5e-5, err_msg=n)
+
+
+def test_tapes_die_by_reference_counting(hip):
+    """no reference cycle through a tape node that keeps its own output (softmax, exp, tanh, pow, max with keepdims): with
+    python's cycle collector switched off, eager training steps must not accumulate device memory"""
+    import gc
+    from lightgrad_amd.autograd.hip import HipDevice
+    rng = np.random.RandomState(3)
+    model = small_model().map_parameters(lambda p: p.hip())
+    ids = hip.from_numpy(np.array([[1, 4, 4, 7], [2, 2, 9, 0]], dtype=np.int32), requires_grad=False)
+    x = hip.from_numpy(rng.uniform(0.5, 2, (4, 6)).astype(np.float32))
+
+    def step():
+        logits = model(ids)
+        loss = (logits * logits).mean() + (x.exp().tanh().sigmoid() ** 2.0).max(axis=1, keepdims=True).sum() + (x ** x).mean()
+        for p in model.parameters():
+            p.zero_grad()
+        x.zero_grad()
+        loss.backward()
+        return loss.item()
+
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        for _ in range(3):
+            step()
+        HipDevice.synchronize()
+        before = HipDevice.pool_stats()["in_use_bytes"]
+        for _ in range(20):
+            step()
+        HipDevice.synchronize()
+        after = HipDevice.pool_stats()["in_use_bytes"]
+    finally:
+        if was_enabled:
+            gc.enable()
+    assert after == before, (before, after)

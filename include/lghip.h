@@ -40,7 +40,7 @@ extern "C" {
 #define LG_EHIP         -2   /* a HIP runtime call failed (message has hipGetErrorString) */
 #define LG_ENOMEM       -3   /* device allocation failed even after trimming the pool */
 #define LG_ENOTINIT     -4   /* lg_init has not been called */
-#define LG_ECOMM        -5   /* RCCL failure (liblghip_comm.so) */
+#define LG_ECOMM        -5   /* RCCL failure (liblghip_comm.so) or a peer-window exchange that gave up waiting (lghip_p2p.h) */
 #define LG_EINDEX       -6   /* an EARLIER kernel met an index / label out of range (reported by the next synchronising call) */
 
 const char* lg_last_error(void);

@@ -118,6 +118,20 @@ PROTOTYPES = {
     "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
 }
 
+# include/lghip_p2p.h: the peer-window gradient exchange, exported by liblghip.so itself (no RCCL)
+P2P_HANDLE_BYTES, P2P_MAX_RANKS = 64, 8
+P2P_SUM, P2P_MAX = 0, 1
+P2P_PROTOTYPES = {
+    "lg_p2p_export": (c_int, [c_int, c_int, c_int64, c_void_p]),          # char handle[64]
+    "lg_p2p_connect": (c_int, [c_void_p]),
+    "lg_p2p_rank": (c_int, [POINTER(c_int), POINTER(c_int), _I64P]),
+    "lg_p2p_allreduce_f32": (c_int, [c_void_p, c_int64, c_int]),
+    "lg_p2p_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
+                                          c_double, c_void_p, c_double, c_int, c_int]),
+    "lg_p2p_disconnect": (c_int, []),
+    "lg_p2p_free": (c_int, []),
+}
+
 COMM_PROTOTYPES = {
     "lg_comm_last_error": (c_char_p, []),
     "lg_comm_get_unique_id": (c_int, [c_void_p]),          # char id[128]
@@ -144,6 +158,8 @@ def load_library(path=LIB_PATH, prototypes=PROTOTYPES, mode=ctypes.DEFAULT_MODE)
             "`make -C lightgrad_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "The HipTensor backend has no CPU fallback." % path)
     lib = ctypes.CDLL(path, mode=mode)
+    if prototypes is PROTOTYPES:
+        prototypes = dict(PROTOTYPES, **P2P_PROTOTYPES)          # both headers are implemented by liblghip.so
     for name, (restype, argtypes) in prototypes.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
         fn.restype, fn.argtypes = restype, argtypes

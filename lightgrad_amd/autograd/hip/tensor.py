@@ -628,6 +628,18 @@ class HipTensor(AbstractTensor):
         # than both: the NEXT step's loss kernel carries the increment (see _advance_step_counter)
         self._advance_step_counter(step_counter, defer=True)
 
+    def _fused_adam_multi_p2p(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
+        """`_fused_adam_multi_dev` of a data-parallel rank: the SAME launch first sums `grad` over the ranks through the peer
+        windows (include/lghip_p2p.h) and also advances the step counter (sharded arrival tickets: no carrier needed)"""
+        for t in (self, grad, m, v):
+            assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
+        assert offsets[-1] == self.numel()
+        flush_lazy_readers(self)
+        flush_lazy_readers(grad)
+        self._flush_step_counter(step_counter)
+        _l.check(_l.lib().lg_p2p_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
+                                                    lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 1))
+
     @staticmethod
     def _new_step_counter(step: int) -> "HipTensor":
         """device-resident optimizer step number for graph-captured training steps: int64[2] = (step, arrival ticket)"""

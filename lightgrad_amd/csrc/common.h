@@ -37,6 +37,7 @@ struct Runtime {
 };
 
 constexpr int LG_STATUS_BAD_INDEX = 1;
+constexpr int LG_STATUS_P2P_TIMEOUT = 2;     // a wait of the peer-window exchange (p2p.hip) gave up: a peer is gone
 
 // after a stream synchronisation: turn a raised status flag into an error (and clear it)
 int check_device_status(const char* who);

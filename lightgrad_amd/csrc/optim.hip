@@ -8,22 +8,9 @@
 //   p += ((-lr) * (m * c1)) * (1 / ((v * c2)^0.5 + eps))   with c1 = 1/(1-b1^t), c2 = 1/(1-b2^t)
 // (the tape's `/` is `a * b**-1`, autograd/ops.py:30-36, hence the reciprocal-then-multiply form)
 #include "common.h"
+#include "adam_common.h"
 
 namespace lg {
-
-struct AdamScalars {
-    float neg_lr, b1, one_minus_b1, b2, one_minus_b2, eps, inv_bias1, inv_bias2, gscale;
-    int   belief, scale_grad;
-};
-
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamScalars& c) {
-    if (c.scale_grad) g = g * c.gscale;
-    m = c.b1 * m + c.one_minus_b1 * g;
-    const float s = c.belief ? g - m : g;
-    v = c.b2 * v + c.one_minus_b2 * (s * s);
-    const float mh = m * c.inv_bias1, vh = v * c.inv_bias2;
-    p = p + (c.neg_lr * mh) * (1.0f / (sqrtf(vh) + c.eps));
-}
 
 __global__ void __launch_bounds__(256) adam_vec4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t nvec, AdamScalars c) {

@@ -1,0 +1,474 @@
+// Peer-window gradient exchange (include/lghip_p2p.h): the data-parallel exchange step of BASELINE config #4 as
+// ordinary kernels on the compute stream - no collective library, no second stream, nothing a hipGraph cannot record.
+// The reference has no distributed code; contract: SURVEY.md 8e.
+//
+// Memory.  A rank's WINDOW is one uncached device allocation (hipDeviceMallocUncached: never held in an L2, so a
+// store that arrives over xGMI - or from another process on the same GPU - is what the next load returns):
+//     flag1   [max_chunks][16] int   flag1[c][s] = epoch of the last push of chunk c by rank s (written by rank s)
+//     flag2   [max_chunks]     int   epoch of the last reduced chunk c (written by the chunk's owner)
+//     recv    [nranks][cap]    float slot s = rank s's contribution to the chunks THIS rank owns
+//     reduced [cap]            float the summed bucket, each chunk written by its owner
+// Peers map it with hipIpcOpenMemHandle.  Remote accesses are stores only (posted writes suit xGMI); all loads are
+// local.  Payload stores are 16-byte `sc0 sc1` (system scope, write-through) and drained by every storing wave before
+// the workgroup's one flag store; payload loads are `sc0 sc1` after a poll + workgroup barrier
+// (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the hand-off table, at system instead of agent scope).
+//
+// Hazards between launches (no flag is ever reset, epochs only grow): a rank enters epoch e+1 only after its epoch-e
+// launch has finished, i.e. after every owner has read the slots of epoch e (its "reduced" flags say so) - so pushes
+// of e+1 never overtake reads of e; an owner stores "reduced" of e+1 only after EVERY rank has pushed for e+1, i.e.
+// after every rank has finished reading "reduced" of e.
+//
+// Deadlock freedom: workgroup c of a rank waits only for workgroup c of other ranks, and pushes before it waits.  The
+// host keeps a launch at <= kMaxChunksPerLaunch workgroups (all resident at once, also with two ranks on one GPU) by
+// giving a workgroup several 1024-float pieces.
+#include "common.h"
+#include "adam_common.h"
+#include "../../include/lghip_p2p.h"
+#include <cstdlib>
+
+namespace lg {
+
+constexpr int     kPiece = 1024;                 // floats per piece: one float4 per thread of a 256-thread workgroup
+constexpr int     kMaxChunksPerLaunch = 448;
+constexpr int     kFlag1Stride = 16;             // ints per chunk: one 64-byte line
+constexpr int     kTicketShards = 16, kTicketStride = 32;
+constexpr int     SC_SYS = 1 | 16;               // sc0 sc1 on the raw buffer builtins
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct P2PCtx {
+    int     rank, nranks;
+    int64_t cap;                                 // floats per slot
+    float*  recv[LG_P2P_MAX_RANKS];              // recv[r]: rank r's window, slot 0
+    float*  reduced[LG_P2P_MAX_RANKS];
+    int*    flag1[LG_P2P_MAX_RANKS];
+    int*    flag2[LG_P2P_MAX_RANKS];
+    int*    local;                               // this rank only: [0] epoch, [1] dead, [32 ...] arrival tickets
+    int*    status;                              // device status flag (runtime.hip)
+    int64_t spin_ticks;                          // a wait gives up after this many ticks of wall_clock64 (100 MHz)
+};
+
+__device__ __forceinline__ void st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int  ld_sys(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// wait until *flag has reached epoch `want`; gives up after x.spin_ticks (or at once when an earlier wait gave up)
+__device__ __forceinline__ void spin_ge(const int* flag, int want, const P2PCtx& x) {
+    if (ld_sys(flag) - want >= 0) return;
+    const int64_t t0 = wall_clock64();
+    for (int n = 1;; ++n) {
+        __builtin_amdgcn_s_sleep(1);
+        if (ld_sys(flag) - want >= 0) return;
+        if ((n & 31) == 0) {
+            if (__hip_atomic_load(x.local + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            if (wall_clock64() - t0 > x.spin_ticks) {
+                __hip_atomic_store(x.local + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_or(x.status, LG_STATUS_P2P_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+    }
+}
+
+// four consecutive floats at element `elem` of a slot of `cap` floats: one 16-byte access when `vec`, else dwords
+__device__ __forceinline__ void slot_store(float* base, int64_t cap, int64_t elem, int nvalid, bool vec, const float (&v)[4]) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, int(cap * 4), 0x00020000);
+    if (vec && nvalid == 4) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(v[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, int(elem * 4), 0, SC_SYS);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), rsrc, int((elem + e) * 4), 0, SC_SYS);
+    }
+}
+
+__device__ __forceinline__ void slot_load(const float* base, int64_t cap, int64_t elem, int nvalid, bool vec, float (&v)[4]) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, int(cap * 4), 0x00020000);
+    if (vec && nvalid == 4) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, int(elem * 4), 0, SC_SYS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(w[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = e < nvalid ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int((elem + e) * 4), 0, SC_SYS)) : 0.f;
+    }
+}
+
+// plain (local bucket) accesses of the same shape
+__device__ __forceinline__ void local_load(const float* p, int nvalid, bool vec, float (&v)[4]) {
+    if (vec && nvalid == 4) {
+        const float4 w = *reinterpret_cast<const float4*>(p);
+        v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = e < nvalid ? p[e] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void local_store(float* p, int nvalid, bool vec, const float (&v)[4]) {
+    if (vec && nvalid == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nvalid) p[e] = v[e];
+    }
+}
+
+// The exchange of ONE chunk by ONE workgroup (all 256 threads call it).  The chunk is `pieces` pieces of 1024 floats
+// starting at element `first` of the bucket `g` (bucket-absolute = slot-relative index), of which elements < `end`
+// exist.  On return g[first .. end) holds the reduced values on every rank (the owner's bits).
+template <bool kMax>
+__device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int chunk, float* g, int64_t first, int64_t end, int pieces, bool vec) {
+    const int tid = threadIdx.x, me = x.rank, n = x.nranks, owner = chunk % n;
+    if (owner != me) {
+        float* slot = x.recv[owner] + int64_t(me) * x.cap;
+        for (int q = 0; q < pieces; ++q) {
+            const int64_t elem = first + int64_t(q) * kPiece + tid * 4;
+            const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
+            if (nvalid > 0) {
+                float v[4];
+                local_load(g + elem, nvalid, vec, v);
+                slot_store(slot, x.cap, elem, nvalid, vec, v);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) {
+            st_sys(x.flag1[owner] + int64_t(chunk) * kFlag1Stride + me, epoch);
+            spin_ge(x.flag2[me] + chunk, epoch, x);
+        }
+        __syncthreads();
+        for (int q = 0; q < pieces; ++q) {
+            const int64_t elem = first + int64_t(q) * kPiece + tid * 4;
+            const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
+            if (nvalid > 0) {
+                float v[4];
+                slot_load(x.reduced[me], x.cap, elem, nvalid, vec, v);
+                local_store(g + elem, nvalid, vec, v);
+            }
+        }
+        return;
+    }
+    if (tid < n && tid != me) spin_ge(x.flag1[me] + int64_t(chunk) * kFlag1Stride + tid, epoch, x);
+    __syncthreads();
+    for (int q = 0; q < pieces; ++q) {
+        const int64_t elem = first + int64_t(q) * kPiece + tid * 4;
+        const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
+        if (nvalid > 0) {
+            float part[LG_P2P_MAX_RANKS][4];
+#pragma unroll
+            for (int r = 0; r < LG_P2P_MAX_RANKS; ++r)
+                if (r < n) {
+                    if (r == me) local_load(g + elem, nvalid, vec, part[r]);
+                    else slot_load(x.recv[me] + int64_t(r) * x.cap, x.cap, elem, nvalid, vec, part[r]);
+                }
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = part[0][e];
+#pragma unroll
+            for (int r = 1; r < LG_P2P_MAX_RANKS; ++r)            // rank order: the same sum in every run
+                if (r < n) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = kMax ? fmaxf(v[e], part[r][e]) : v[e] + part[r][e];
+                }
+            local_store(g + elem, nvalid, vec, v);
+#pragma unroll
+            for (int r = 0; r < LG_P2P_MAX_RANKS; ++r)
+                if (r < n && r != me) slot_store(x.reduced[r], x.cap, elem, nvalid, vec, v);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < n && tid != me) st_sys(x.flag2[tid] + chunk, epoch);
+}
+
+// The workgroup has finished chunk `a` of `total`: the LAST one of the launch publishes the epoch (and the optimizer's
+// step number).  Arrival tickets are sharded 16 ways (one contended word costs ~11 ns per arrival; MI355X_MICROARCH.md,
+// price list, 'fanin') and zero again when the launch ends.  Every workgroup has read epoch / step before it arrives.
+__device__ __forceinline__ void arrive(const P2PCtx& x, int a, int total, int epoch, int64_t* step) {
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int* tickets = x.local + 32;
+    const int shard = a % kTicketShards;
+    const int in_shard = (total - shard + kTicketShards - 1) / kTicketShards;
+    int* t = tickets + shard * kTicketStride;
+    if (__hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_shard - 1) return;
+    __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int shards = total < kTicketShards ? total : kTicketShards;
+    int* top = tickets + kTicketShards * kTicketStride;
+    if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != shards - 1) return;
+    __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(x.local, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (step) step[0] = step[0] + 1;
+}
+
+template <bool kMax>
+__global__ void __launch_bounds__(256) p2p_allreduce(P2PCtx x, float* buf, int64_t n, int pieces, int vec) {
+    const int epoch = x.local[0] + 1;
+    const int c = blockIdx.x;
+    const int64_t first = int64_t(c) * pieces * kPiece;
+    exchange_chunk<kMax>(x, epoch, c, buf, first, n, pieces, vec != 0);
+    arrive(x, c, gridDim.x, epoch, nullptr);
+}
+
+// ---- the optimizer launch with the exchange in front ------------------------------------------------------------------
+constexpr int kP2PMaxSegments = 64;
+struct P2PSegments {
+    int     nseg, nseg_total, first;             // as AdamSegments (optim.hip)
+    int     pieces;                              // 1024-float pieces per workgroup
+    int     total_chunks;                        // workgroups with work in this launch
+    int     chunk_base[kP2PMaxSegments];         // index of a segment's first chunk among the launch's chunks
+    int64_t offsets[kP2PMaxSegments + 1];
+};
+
+__global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                      P2PSegments seg, AdamScalars c, int64_t* __restrict__ step, double b1, double b2,
+                                                      int advance, int base_aligned, P2PCtx x) {
+    __shared__ float inv_bias[2];
+    const int j = blockIdx.y;
+    const int64_t begin = seg.offsets[j], end = seg.offsets[j + 1];
+    const int64_t first = begin + int64_t(blockIdx.x) * seg.pieces * kPiece;
+    if (first >= end) return;                                      // workgroup-uniform; such workgroups take no ticket
+    const int epoch = x.local[0] + 1;
+    if (threadIdx.x == 0) {
+        const double t = double(step[0] * seg.nseg_total + seg.first + j + 1);
+        inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
+        inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
+    }
+    const bool vec = base_aligned && (begin & 3) == 0;
+    const int chunk = seg.chunk_base[j] + blockIdx.x;
+    exchange_chunk<false>(x, epoch, chunk, g, first, end, seg.pieces, vec);       // barriers inside: inv_bias is visible after it
+    c.inv_bias1 = inv_bias[0];
+    c.inv_bias2 = inv_bias[1];
+    for (int q = 0; q < seg.pieces; ++q) {
+        const int64_t elem = first + int64_t(q) * kPiece + threadIdx.x * 4;
+        const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
+        if (nvalid > 0) {
+            float G[4], P[4], M[4], V[4];
+            local_load(g + elem, nvalid, vec, G);                  // this thread's own stores of the reduced values
+            local_load(p + elem, nvalid, vec, P);
+            local_load(m + elem, nvalid, vec, M);
+            local_load(v + elem, nvalid, vec, V);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_elem(P[e], G[e], M[e], V[e], c);
+            local_store(p + elem, nvalid, vec, P);
+            local_store(m + elem, nvalid, vec, M);
+            local_store(v + elem, nvalid, vec, V);
+        }
+    }
+    arrive(x, chunk, seg.total_chunks, epoch, advance ? step : nullptr);
+}
+
+// ---- host state ---------------------------------------------------------------------------------------------------------
+struct P2PState {
+    bool    exported = false, connected = false;
+    int     rank = -1, nranks = 0;
+    int64_t cap = 0;
+    int     max_chunks = 0;
+    char*   window = nullptr;
+    size_t  off_flag1 = 0, off_flag2 = 0, off_recv = 0, off_reduced = 0, bytes = 0;
+    void*   peer[LG_P2P_MAX_RANKS] = {};
+    int*    local = nullptr;
+    const char* memory_kind = "";
+    int64_t spin_ticks = int64_t(LG_P2P_TIMEOUT_S) * 100000000;
+};
+
+static P2PState& st() {
+    static P2PState s;
+    return s;
+}
+
+static size_t round256(size_t b) { return (b + 255) & ~size_t(255); }
+
+static P2PCtx make_ctx() {
+    P2PState& S = st();
+    P2PCtx x;
+    memset(&x, 0, sizeof(x));
+    x.rank = S.rank;
+    x.nranks = S.nranks;
+    x.cap = S.cap;
+    for (int r = 0; r < S.nranks; ++r) {
+        char* base = r == S.rank ? S.window : static_cast<char*>(S.peer[r]);
+        x.flag1[r] = reinterpret_cast<int*>(base + S.off_flag1);
+        x.flag2[r] = reinterpret_cast<int*>(base + S.off_flag2);
+        x.recv[r] = reinterpret_cast<float*>(base + S.off_recv);
+        x.reduced[r] = reinterpret_cast<float*>(base + S.off_reduced);
+    }
+    x.local = S.local;
+    x.status = rt().status_dev;
+    x.spin_ticks = S.spin_ticks;
+    return x;
+}
+
+}  // namespace lg
+
+using namespace lg;
+
+extern "C" int lg_p2p_export(int rank, int nranks, int64_t capacity_floats, char handle[LG_P2P_HANDLE_BYTES]) {
+    LG_REQUIRE_INIT();
+    P2PState& S = st();
+    LG_ARG(!S.exported, "lg_p2p_export: this process already has a window (lg_p2p_free first)");
+    LG_ARG(handle != nullptr, "lg_p2p_export: NULL handle buffer");
+    LG_ARG(nranks >= 1 && nranks <= LG_P2P_MAX_RANKS && rank >= 0 && rank < nranks, "lg_p2p_export: rank %d of %d (at most %d ranks: one node)",
+           rank, nranks, LG_P2P_MAX_RANKS);
+    LG_ARG(capacity_floats >= 1 && capacity_floats <= (int64_t(1) << 28), "lg_p2p_export: capacity %lld floats outside 1 .. 2^28", (long long)capacity_floats);
+    static_assert(sizeof(hipIpcMemHandle_t) <= LG_P2P_HANDLE_BYTES, "hipIpcMemHandle_t does not fit the handle buffer");
+    S.cap = (capacity_floats + kPiece - 1) / kPiece * kPiece;
+    S.max_chunks = int(S.cap / kPiece) + kP2PMaxSegments;
+    S.off_flag1 = 0;
+    S.off_flag2 = round256(S.off_flag1 + size_t(S.max_chunks) * kFlag1Stride * 4);
+    S.off_recv = round256(S.off_flag2 + size_t(S.max_chunks) * 4);
+    S.off_reduced = round256(S.off_recv + size_t(nranks) * S.cap * 4);
+    S.bytes = round256(S.off_reduced + size_t(S.cap) * 4);
+    void* w = nullptr;
+    S.memory_kind = "uncached";
+    if (hipExtMallocWithFlags(&w, S.bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        S.memory_kind = "fine-grained";
+        if (hipExtMallocWithFlags(&w, S.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            S.memory_kind = "hipMalloc";
+            LG_HIP(hipMalloc(&w, S.bytes));
+        }
+    }
+    S.window = static_cast<char*>(w);
+    LG_HIP(hipMemset(S.window, 0, S.bytes));
+    LG_HIP(hipMalloc(reinterpret_cast<void**>(&S.local), 4096));
+    LG_HIP(hipMemset(S.local, 0, 4096));
+    LG_HIP(hipDeviceSynchronize());                               // the zeros are in place before any peer learns the handle
+    hipIpcMemHandle_t h;
+    LG_HIP(hipIpcGetMemHandle(&h, S.window));
+    memset(handle, 0, LG_P2P_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    S.rank = rank;
+    S.nranks = nranks;
+    S.exported = true;
+    if (const char* ms = getenv("LG_P2P_TIMEOUT_MS"))             // tests of the lost-peer path
+        if (atoll(ms) > 0) S.spin_ticks = atoll(ms) * 100000;
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_connect(const char* handles) {
+    LG_REQUIRE_INIT();
+    P2PState& S = st();
+    LG_ARG(S.exported && !S.connected, "lg_p2p_connect: call lg_p2p_export first (once)");
+    LG_ARG(handles != nullptr, "lg_p2p_connect: NULL");
+    for (int r = 0; r < S.nranks; ++r) {
+        if (r == S.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + size_t(r) * LG_P2P_HANDLE_BYTES, sizeof(h));
+        hipError_t e = hipIpcOpenMemHandle(&S.peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (int q = 0; q < r; ++q)
+                if (q != S.rank && S.peer[q]) { (void)hipIpcCloseMemHandle(S.peer[q]); S.peer[q] = nullptr; }
+            set_error("lg_p2p_connect: hipIpcOpenMemHandle of rank %d's window failed: %s", r, hipGetErrorString(e));
+            return LG_ECOMM;
+        }
+    }
+    S.connected = true;
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_rank(int* rank, int* nranks, int64_t* capacity_floats) {
+    P2PState& S = st();
+    LG_ARG(S.exported, "lg_p2p_rank: no window");
+    if (rank) *rank = S.rank;
+    if (nranks) *nranks = S.nranks;
+    if (capacity_floats) *capacity_floats = S.cap;
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_allreduce_f32(float* buf, int64_t n, int op) {
+    LG_REQUIRE_INIT();
+    P2PState& S = st();
+    LG_ARG(S.connected, "lg_p2p_allreduce_f32: lg_p2p_export / lg_p2p_connect first");
+    LG_ARG(n >= 0 && (n == 0 || buf), "lg_p2p_allreduce_f32: bad buffer");
+    LG_ARG(op == LG_P2P_SUM || op == LG_P2P_MAX, "lg_p2p_allreduce_f32: unknown op %d", op);
+    const P2PCtx x = make_ctx();
+    const int vec = aligned16(buf) ? 1 : 0;
+    for (int64_t done = 0; done < n; done += S.cap) {             // a launch moves at most one window's worth
+        const int64_t len = n - done < S.cap ? n - done : S.cap;
+        const int64_t units = (len + kPiece - 1) / kPiece;
+        const int pieces = int((units + kMaxChunksPerLaunch - 1) / kMaxChunksPerLaunch);
+        const unsigned grid = unsigned((units + pieces - 1) / pieces);
+        if (op == LG_P2P_SUM) hipLaunchKernelGGL(p2p_allreduce<false>, dim3(grid), dim3(256), 0, rt().stream, x, buf + done, len, pieces, vec);
+        else                  hipLaunchKernelGGL(p2p_allreduce<true>, dim3(grid), dim3(256), 0, rt().stream, x, buf + done, len, pieces, vec);
+        LG_CHECK_LAUNCH();
+    }
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v, int nseg, const int64_t* offsets,
+                                         double lr, double b1, double b2, double eps, int64_t* step, double gscale,
+                                         int belief, int advance) {
+    LG_REQUIRE_INIT();
+    P2PState& S = st();
+    LG_ARG(S.connected, "lg_p2p_adam_multi_dev_f32: lg_p2p_export / lg_p2p_connect first");
+    LG_ARG(nseg >= 1, "lg_p2p_adam_multi_dev_f32: %d segments", nseg);
+    LG_ARG(p && g && m && v && step && offsets, "lg_p2p_adam_multi_dev_f32: NULL pointer");
+    for (int j = 0; j < nseg; ++j) LG_ARG(offsets[j + 1] >= offsets[j], "lg_p2p_adam_multi_dev_f32: offsets must be non-decreasing");
+    LG_ARG(offsets[0] >= 0 && offsets[nseg] <= S.cap, "lg_p2p_adam_multi_dev_f32: the bucket (%lld floats) exceeds the window (%lld)",
+           (long long)offsets[nseg], (long long)S.cap);
+    const P2PCtx x = make_ctx();
+    const AdamScalars c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
+    const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
+    for (int first = 0; first < nseg; first += kP2PMaxSegments) {  // groups of segments: one launch (and one epoch) each
+        const int count = nseg - first < kP2PMaxSegments ? nseg - first : kP2PMaxSegments;
+        P2PSegments seg;
+        seg.nseg = count;
+        seg.nseg_total = nseg;
+        seg.first = first;
+        int64_t units = 0, longest = 0;
+        for (int j = 0; j < count; ++j) {
+            const int64_t len = offsets[first + j + 1] - offsets[first + j];
+            units += (len + kPiece - 1) / kPiece;
+            if (len > longest) longest = len;
+        }
+        for (int j = 0; j <= count; ++j) seg.offsets[j] = offsets[first + j];
+        if (longest == 0) continue;
+        // pieces per workgroup: smallest count that keeps the launch's workgroups with work within the resident limit
+        int pieces = int((units + kMaxChunksPerLaunch - 1) / kMaxChunksPerLaunch);
+        for (;; ++pieces) {
+            int64_t chunks = 0;
+            for (int j = 0; j < count; ++j) chunks += (offsets[first + j + 1] - offsets[first + j] + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece);
+            if (chunks <= kMaxChunksPerLaunch + count) break;
+        }
+        seg.pieces = pieces;
+        int total = 0;
+        for (int j = 0; j < count; ++j) {
+            seg.chunk_base[j] = total;
+            total += int((offsets[first + j + 1] - offsets[first + j] + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece));
+        }
+        seg.total_chunks = total;
+        LG_ARG(total <= S.max_chunks, "lg_p2p_adam_multi_dev_f32: %d chunks exceed the window's %d flags", total, S.max_chunks);
+        const unsigned grid_x = unsigned((longest + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece));
+        const int adv = (advance && first + count >= nseg) ? 1 : 0;             // the last group alone advances the step number
+        hipLaunchKernelGGL(adam_multi_p2p, dim3(grid_x, count), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2, adv, base_aligned, x);
+        LG_CHECK_LAUNCH();
+    }
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_disconnect(void) {
+    P2PState& S = st();
+    if (!S.connected) return LG_OK;
+    LG_HIP(hipStreamSynchronize(rt().stream));
+    for (int r = 0; r < S.nranks; ++r)
+        if (r != S.rank && S.peer[r]) { (void)hipIpcCloseMemHandle(S.peer[r]); S.peer[r] = nullptr; }
+    S.connected = false;
+    return LG_OK;
+}
+
+extern "C" int lg_p2p_free(void) {
+    P2PState& S = st();
+    if (!S.exported) return LG_OK;
+    LG_ARG(!S.connected, "lg_p2p_free: lg_p2p_disconnect first");
+    (void)hipFree(S.window);
+    (void)hipFree(S.local);
+    S = P2PState();
+    return LG_OK;
+}

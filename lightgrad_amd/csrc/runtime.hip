@@ -6,6 +6,7 @@
 // the pool below is a best-fit free list keyed by size, safe without events
 // because every consumer of a block is enqueued on the one library stream.
 #include "common.h"
+#include "../../include/lghip_p2p.h"
 #include <cstdarg>
 #include <map>
 #include <unordered_map>
@@ -70,6 +71,11 @@ int check_device_status(const char* who) {
     if (R.status_host == nullptr) return LG_OK;
     const int status = __atomic_exchange_n(R.status_host, 0, __ATOMIC_ACQ_REL);
     if (status == 0) return LG_OK;
+    if (status & LG_STATUS_P2P_TIMEOUT) {
+        set_error("%s: a peer-window exchange launched earlier waited more than %d s for another rank (lghip_p2p.h); the gradient "
+                  "buckets and parameters of this rank are not to be trusted (device status %d)", who, LG_P2P_TIMEOUT_S, status);
+        return LG_ECOMM;
+    }
     set_error("%s: a kernel launched earlier met an index or label outside its axis (device status %d); results of that "
               "launch hold all-ones bytes / NaN where the index was bad", who, status);
     return LG_EINDEX;

@@ -10,7 +10,9 @@ addition for BASELINE config #4.  Design:
   * `mse.backward` carries no 1/N (loss.py:12), so the all-reduce SUM equals the gradient of the
     concatenated batch; the mean (x 1/world) is folded into the optimizer (`grad_scale`).
 
-Two communicators implement the same interface:
+Communicators with the same interface:
+  PeerWindowCommunicator  HipTensor buckets, hand-written exchange through peer-mapped device memory (include/lghip_p2p.h):
+                    ordinary kernels, and the gradient exchange fused into the optimizer launch
   RcclCommunicator  HipTensor buckets, RCCL through liblghip_comm.so (include/lghip_comm.h)
   GlooCommunicator  CpuTensor buckets, torch.distributed/gloo - lets the bucket / scaling /
                     determinism logic be tested with world_size 2 on a CPU-only machine
@@ -146,6 +148,38 @@ def _exchange_unique_id(rank, make_id, path, timeout=300.0):
     raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout))
 
 
+def _exchange_blobs(rank, world, blob, prefix, timeout=300.0):
+    """every rank publishes `blob` as <prefix>.<rank> (atomic rename) and reads the others'; returns the list by rank"""
+    tmp = "%s.%d.tmp.%d" % (prefix, rank, os.getpid())
+    with open(tmp, "wb") as f:
+        f.write(blob)
+    os.replace(tmp, "%s.%d" % (prefix, rank))
+    out, deadline = [], time.time() + timeout
+    for r in range(world):
+        while True:
+            try:
+                with open("%s.%d" % (prefix, r), "rb") as f:
+                    data = f.read()
+                if len(data) == len(blob):
+                    out.append(data)
+                    break
+            except FileNotFoundError:
+                pass
+            if time.time() > deadline:
+                raise TimeoutError("rank %d: nothing from rank %d at %s.%d after %.0f s" % (rank, r, prefix, r, timeout))
+            time.sleep(0.005)
+    return out
+
+
+def _job_rendezvous_path():
+    """a path unique to this job that every rank of it derives alike (lightgrad_amd.launch sets it; torch.distributed.run: its pid)"""
+    path = os.environ.get("LIGHTGRAD_RCCL_ID_FILE")
+    if path is None:
+        tag = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.getppid())
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lightgrad_rccl_%s.id" % tag)
+    return path
+
+
 class _c_stdout_to_stderr(object):
     """redirect file descriptor 1 to file descriptor 2 for the duration of a `with` block (C libraries included)"""
 
@@ -181,12 +215,9 @@ class RcclCommunicator(Communicator):
         self._L = L
         self._lib = L.comm_lib()
         if id_path is None:
-            id_path = os.environ.get("LIGHTGRAD_RCCL_ID_FILE")      # set per job by lightgrad_amd.launch
-        if id_path is None:
-            # under torch.distributed.run: all ranks of one launch are children of the same launcher process (torch.distributed.run agent):
-            # its pid makes the rendezvous file unique per launch, so a stale file of a crashed run is never read
-            tag = "%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.getppid())
-            id_path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "lightgrad_rccl_%s.id" % tag)
+            # set per job by lightgrad_amd.launch; under torch.distributed.run all ranks of one launch are children of the same
+            # launcher process, whose pid makes the rendezvous file unique per launch: a stale file of a crashed run is never read
+            id_path = _job_rendezvous_path()
         self._id_path = id_path
 
         def make_id():
@@ -249,6 +280,79 @@ class RcclCommunicator(Communicator):
         self._L.comm_check(self._lib.lg_comm_destroy())
 
 
+class PeerWindowCommunicator(Communicator):
+    """GPU ranks of ONE node that exchange through peer-mapped device memory (include/lghip_p2p.h, csrc/p2p.hip): every
+    collective is one ordinary kernel launch on the compute stream - capturable in a hipGraph, no collective library, no
+    second stream - and the gradient exchange can ride INSIDE the optimizer launch (`fused_optimizer_exchange`:
+    DataParallel.attach hands the optimizer this communicator, sync_gradients() then launches nothing).
+
+    Works over xGMI between the GPUs of a node and between rank processes that SHARE one GPU (hipIpc handles are per
+    process, not per device) - which is how the multi-rank device path is tested on one-GPU machines."""
+    fused_optimizer_exchange = True
+
+    def __init__(self, rank=None, world_size=None, id_path=None, capacity_floats=1 << 22):
+        from .autograd.hip import lib as L
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+        self._L, self._lib = L, L.lib()
+        self._prefix = (_job_rendezvous_path() if id_path is None else id_path) + ".p2p"
+        handle = ctypes.create_string_buffer(L.P2P_HANDLE_BYTES)
+        L.check(self._lib.lg_p2p_export(self.rank, self.world_size, int(capacity_floats), handle))
+        self._open = True
+        blobs = _exchange_blobs(self.rank, self.world_size, handle.raw, self._prefix)
+        L.check(self._lib.lg_p2p_connect(ctypes.create_string_buffer(b"".join(blobs), len(blobs) * L.P2P_HANDLE_BYTES)))
+        self.barrier()                  # every rank has mapped every window ...
+        try:
+            os.remove("%s.%d" % (self._prefix, self.rank))       # ... so nobody reads this file any more
+        except OSError:
+            pass
+
+    def _check_flat(self, flat):
+        assert isinstance(flat, HipTensor) and flat.is_contiguous() and flat.dtype == np.float32
+        from .autograd.hip.tensor import flush_lazy_readers
+        flush_lazy_readers(flat)        # collectives write in place
+        return flat
+
+    def allreduce_sum_(self, flat, forked=False):
+        self._check_flat(flat)
+        self._L.check(self._lib.lg_p2p_allreduce_f32(flat.ptr, flat.numel(), self._L.P2P_SUM))
+        return flat
+
+    def allreduce_max_(self, flat):
+        self._check_flat(flat)
+        self._L.check(self._lib.lg_p2p_allreduce_f32(flat.ptr, flat.numel(), self._L.P2P_MAX))
+        return flat
+
+    def broadcast_(self, flat, root=0):
+        self._check_flat(flat)
+        if self.rank != root:
+            with Gradients.no_grad():
+                flat.fill(0.0)          # x + 0 + ... + 0: the root's values (a -0.0 arrives as +0.0)
+        return self.allreduce_sum_(flat)
+
+    def barrier(self):
+        token = HipTensor.zeros((1,), requires_grad=False)
+        self.allreduce_sum_(token)
+        self._L.check(self._lib.lg_sync())
+
+    def ranks_seen(self) -> int:
+        r, n, cap = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int64(0)
+        self._L.check(self._lib.lg_p2p_rank(ctypes.byref(r), ctypes.byref(n), ctypes.byref(cap)))
+        assert r.value == self.rank
+        return n.value
+
+    def close(self):
+        if not self._open:
+            return
+        self._open = False
+        self.barrier()                                            # every rank has finished its launches
+        self._L.check(self._lib.lg_p2p_disconnect())
+        # nobody maps my window any more once every rank has said so (the files are tiny and stay: a rank that removed its
+        # own could be gone before a slower peer has read it; lightgrad_amd.launch clears the job's directory)
+        _exchange_blobs(self.rank, self.world_size, b"bye", self._prefix + ".bye")
+        self._L.check(self._lib.lg_p2p_free())
+
+
 def _flat_and_views(cls, shapes):
     """one dense fp32 bucket of class `cls` and a view of it per shape (no copies)"""
     sizes = [int(np.prod(s, dtype=np.int64)) if len(s) else 1 for s in shapes]
@@ -301,6 +405,7 @@ class DataParallel(object):
         self.grad_scale = 1.0 / comm.world_size
         self.offsets = tuple(int(o) for o in np.concatenate([[0], np.cumsum([p.numel() for p in self.parameters])]))
         self.flat_parameters = None
+        self._exchange_in_optimizer = False
         if flatten:
             # re-home the parameter VALUES into one bucket too (the tensor objects the model holds stay the same):
             # lets the optimizer update every parameter with a single launch
@@ -348,6 +453,12 @@ class DataParallel(object):
         assert self.flat_parameters is not None, "DataParallel(..., flatten=True) first"
         assert tuple(optimizer.parameters) == self.parameters
         optimizer.use_flat_buckets(self.flat_parameters, self.bucket, self.offsets)
+        if getattr(self.comm, "fused_optimizer_exchange", False) and self._exchange_needed():
+            # the gradient exchange happens INSIDE the optimizer's launch (lg_p2p_adam_multi_dev_f32): nothing to overlap,
+            # nothing for sync_gradients() to launch
+            optimizer.use_peer_exchange(self.comm)
+            self._exchange_in_optimizer = True
+            self.set_overlap(False)
         return optimizer
 
     def broadcast_parameters(self, root: int = 0):
@@ -367,6 +478,8 @@ class DataParallel(object):
         self._writes_seen, self._exchange_started = 0, False
         if not self._exchange_needed():
             return
+        if self._exchange_in_optimizer:
+            return                                # optimizer.step() sums the bucket over the ranks in its own launch
         if started:
             self.comm.join()                      # the optimizer (next on the compute stream) waits for the exchange
             return

@@ -71,9 +71,9 @@ def spawn_ranks(nproc: int, argv, timeout: float = None, poll: float = 0.05, gra
         return code
     finally:
         _stop(children, grace)
-        for name in (id_file, id_file + ".tmp"):
+        for name in os.listdir(workdir):              # rendezvous files of the communicators (RCCL id, peer-window handles)
             try:
-                os.remove(name)
+                os.remove(os.path.join(workdir, name))
             except OSError:
                 pass
         try:

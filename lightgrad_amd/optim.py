@@ -73,6 +73,7 @@ class Adam(Optimizer):
         self.fused, self.grad_scale, self.device_step = fused, grad_scale, device_step
         self._step_counter = None
         self._flat = None               # (flat_params, flat_m, flat_v, offsets) once use_flat_buckets() was called
+        self._peer_exchange = None
 
     def second_moment_input(self, grad, m):
         return grad
@@ -96,6 +97,12 @@ class Adam(Optimizer):
                       cls.zeros(flat_params.shape, requires_grad=False), tuple(int(o) for o in offsets))
         self._step_counter = flat_params._new_step_counter(0)
 
+    def use_peer_exchange(self, comm) -> None:
+        """data parallel with a communicator whose exchange rides in the optimizer launch (dist.PeerWindowCommunicator):
+        step() first sums the flat gradient bucket over the ranks, in the same kernel"""
+        assert self._flat is not None and hasattr(self._flat[0], "_fused_adam_multi_p2p"), "use_flat_buckets() first"
+        self._peer_exchange = comm
+
     @Gradients.no_grad()
     def step(self) -> None:
         n_params = len(self.parameters)
@@ -103,7 +110,8 @@ class Adam(Optimizer):
             for p in self.parameters:
                 p._materialize_zero_grad()        # parameters no gradient reached since zero_grad
             flat_p, flat_m, flat_v, offsets = self._flat
-            flat_p._fused_adam_multi_dev(self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2, self.eps,
+            update = flat_p._fused_adam_multi_dev if self._peer_exchange is None else flat_p._fused_adam_multi_p2p
+            update(self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2, self.eps,
                                          self._step_counter, self.grad_scale, self.belief)   # advances the device counter too
             self.t += n_params
             return

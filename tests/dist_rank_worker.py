@@ -1,0 +1,180 @@
+"""One rank of a multi-process GPU test (started by tests/rank_spawner.py through the `spawn_ranks` fixture; RANK / WORLD_SIZE /
+MASTER_* / LIGHTGRAD_RCCL_ID_FILE come from the environment).  Every rank binds HIP device 0: the ranks SHARE the one GPU of
+the test box.  Modes:
+
+  train        the data-parallel MLP training loop of tests/test_dist_cpu.py on HipTensor replicas; writes rank<r>.npz
+               --comm host   collectives staged through the host (dist.HostStagedCommunicator: D2H, gloo, H2D)
+               --comm p2p    collectives through peer-mapped device memory (dist.PeerWindowCommunicator, csrc/p2p.hip);
+                             with --fused 1 the exchange rides inside the optimizer launch, with --graph 1 the steps after
+                             the first are replayed from a hipGraph
+  collectives  all-reduce SUM / MAX, broadcast, barrier of the peer-window communicator on awkward sizes, checked in place
+  lost_peer    rank 1 never joins a collective: rank 0 must get HipError (LG_ECOMM) at its next synchronisation, not hang
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+os.environ["LIGHTGRAD_HIP_DEVICE"] = "0"          # every rank on the one GPU
+
+import faulthandler  # noqa: E402
+import numpy as np  # noqa: E402
+
+faulthandler.dump_traceback_later(int(os.environ.get("LIGHTGRAD_WORKER_DUMP_AFTER", "100")), exit=False)   # a stuck rank says where
+
+
+def make_comm(kind, rank, world):
+    if kind == "host":
+        import torch.distributed as dist
+        from lightgrad_amd.dist import HostStagedCommunicator
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+        return HostStagedCommunicator()
+    from lightgrad_amd.dist import PeerWindowCommunicator
+    return PeerWindowCommunicator(rank, world, capacity_floats=1 << 16)     # small window: large buffers take several launches
+
+
+def train(args, rank, world):
+    import lightgrad_amd as light
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipGraph
+    from lightgrad_amd.dist import DataParallel
+    from test_cpu_backend import MLP
+    import np_oracle as O
+    comm = make_comm(args.comm, rank, world)
+    np.random.seed(100 + rank)                     # deliberately different init per rank: broadcast must fix it
+    model = MLP(20, 16, 10).map_parameters(lambda p: p.hip())
+    dp = DataParallel(model.parameters(), comm, flatten=args.fused, overlap=args.overlap)
+    w_start = {n: p.numpy().copy() for n, p in model.named_parameters()}
+    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, eps=0.05, grad_scale=dp.grad_scale, fused=args.fused, device_step=args.fused)
+    if args.fused:
+        dp.attach(opt)                             # flat buckets; with the peer-window communicator: exchange inside the optimizer launch
+    in_optimizer = dp._exchange_in_optimizer
+    _, x, onehot, _ = O.synthetic_mlp_problem(500 + rank, 20, 16, 10, 8)     # own batch per rank
+    xt, tt = HipTensor.from_numpy(x), HipTensor.from_numpy(onehot)
+
+    def step():
+        l = light.loss.mse(model(xt), tt)
+        opt.zero_grad()
+        l.backward()
+        dp.sync_gradients()
+        g = None if in_optimizer else {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+        opt.step()
+        if in_optimizer:                           # the bucket holds the summed gradient once the optimizer launch has run
+            g = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+        return l, g
+    losses = []
+    l, g_sum = step()
+    losses.append(l.item())
+    w_after_first = {n: p.numpy().copy() for n, p in model.named_parameters()}
+    if args.graph:
+        assert args.fused
+        graph = HipGraph()
+        with graph.capture():
+            gl = light.loss.mse(model(xt), tt)
+            opt.zero_grad()
+            gl.backward()
+            dp.sync_gradients()
+            opt.step()
+        opt.t -= len(opt.parameters)
+        for _ in range(args.steps - 1):
+            graph.replay()
+            opt.on_graph_replay()
+            losses.append(gl.item())
+    else:
+        for _ in range(args.steps - 1):
+            l, _ = step()
+            losses.append(l.item())
+    np.savez(os.path.join(args.out, "rank%d.npz" % rank), x=x, onehot=onehot, losses=np.asarray(losses),
+             digest=np.asarray(dp.parameter_digest()), in_optimizer=np.asarray(in_optimizer),
+             **{"w0/" + n: v for n, v in w_start.items()}, **{"g/" + n: v for n, v in g_sum.items()},
+             **{"w1/" + n: v for n, v in w_after_first.items()},
+             **{"wf/" + n: p.numpy() for n, p in model.named_parameters()})
+    comm.close()
+    if args.comm == "host":
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def collectives(args, rank, world):
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipDevice
+    comm = make_comm("p2p", rank, world)
+    assert comm.ranks_seen() == world
+    rngs = [np.random.RandomState(7000 + r) for r in range(world)]
+    # sizes: one value, not a multiple of 4, exactly one piece, several pieces + tail, beyond the window (65536 floats)
+    for n in (1, 3, 1024, 5000, 65536, 200001):
+        parts = [g.uniform(-1, 1, n).astype(np.float32) for g in rngs]
+        want_sum = parts[0].copy()
+        for q in parts[1:]:
+            want_sum = want_sum + q                            # rank order, fp32: the kernel's bits
+        want_max = np.maximum.reduce(parts)
+        t = HipTensor.from_numpy(parts[rank], requires_grad=False)
+        comm.allreduce_sum_(t)
+        np.testing.assert_array_equal(t.numpy(), want_sum, err_msg="sum n=%d" % n)
+        t = HipTensor.from_numpy(parts[rank], requires_grad=False)
+        comm.allreduce_max_(t)
+        np.testing.assert_array_equal(t.numpy(), want_max, err_msg="max n=%d" % n)
+        for root in range(world):
+            t = HipTensor.from_numpy(parts[rank], requires_grad=False)
+            comm.broadcast_(t, root)
+            np.testing.assert_array_equal(t.numpy(), parts[root], err_msg="broadcast n=%d root=%d" % (n, root))
+    # an unaligned view of a bucket (element offset 1): the dword path
+    base = np.zeros(4099, np.float32)
+    base[1:] = rngs[0].uniform(-1, 1, 4098).astype(np.float32) * (rank + 1)
+    t = HipTensor.from_numpy(base, requires_grad=False)
+    view = HipTensor(t.data, (4098,), None, t.offset + 1, t.dtype, requires_grad=False)      # a view (getitem copies)
+    assert view.is_contiguous() and view.ptr % 16 == 4
+    comm.allreduce_sum_(view)
+    want = np.zeros(4098, np.float32)
+    for r in range(world):
+        c = (base[1:] / np.float32(rank + 1)) * np.float32(r + 1)
+        want = c if r == 0 else want + c
+    np.testing.assert_allclose(t.numpy()[1:], want, rtol=1e-6)
+    assert t.numpy()[0] == 0
+    # many collectives back to back without a host synchronisation in between (epochs, no flag is ever reset)
+    t = HipTensor.from_numpy(np.full(2048, float(rank + 1), np.float32), requires_grad=False)
+    for _ in range(200):
+        comm.allreduce_max_(t)
+    comm.allreduce_sum_(t)
+    HipDevice.synchronize()
+    np.testing.assert_array_equal(t.numpy(), np.full(2048, float(world * world), np.float32))
+    comm.close()
+    print("rank %d: collectives ok" % rank)
+
+
+def lost_peer(args, rank, world):
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipDevice, lib as L
+    comm = make_comm("p2p", rank, world)           # includes one barrier: both ranks are connected
+    if rank != 0:
+        time.sleep(4.0)                            # never joins the collective below; exits without close()
+        return
+    t = HipTensor.from_numpy(np.ones(4096, np.float32), requires_grad=False)
+    t0 = time.time()
+    comm.allreduce_sum_(t)
+    try:
+        HipDevice.synchronize()
+    except L.HipError as e:
+        took = time.time() - t0
+        assert "peer-window exchange" in str(e) and "liblghip error -5" in str(e), str(e)
+        assert took < 3.0, took
+        print("rank 0: lost peer reported after %.2f s: %s" % (took, e))
+        return
+    raise AssertionError("a collective without its peer returned normally")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="train")
+    ap.add_argument("--comm", default="p2p")
+    ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--out", default=".")
+    a = ap.parse_args()
+    a.overlap, a.fused, a.graph = bool(a.overlap), bool(a.fused), bool(a.graph)
+    {"train": train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))

@@ -25,6 +25,25 @@ def test_core_library_exports_every_declared_symbol():
         assert getattr(handle, n) is not None
 
 
+def test_core_library_exports_the_peer_window_exchange():
+    names = declared("lghip_p2p.h")
+    assert len(names) == 7, names
+    assert sorted(hiplib.P2P_PROTOTYPES) == names, "python prototypes and include/lghip_p2p.h disagree"
+    handle = hiplib.load_library()
+    for n in names:
+        assert getattr(handle, n) is not None
+    text = open(os.path.join(ROOT, "include", "lghip_p2p.h")).read()
+    assert "#define LG_P2P_HANDLE_BYTES %d" % hiplib.P2P_HANDLE_BYTES in text
+    assert re.search(r"#define LG_P2P_MAX_RANKS\s+%d" % hiplib.P2P_MAX_RANKS, text)
+    # without lg_init nothing is allocated or exported
+    buf = ctypes.create_string_buffer(hiplib.P2P_HANDLE_BYTES)
+    n = ctypes.c_int(0)
+    handle.lg_device_count(ctypes.byref(n))
+    if n.value == 0:
+        assert handle.lg_p2p_export(0, 2, 1024, buf) == -4          # LG_ENOTINIT
+        assert handle.lg_p2p_allreduce_f32(None, 0, 0) == -4
+
+
 def test_comm_library_exports_every_declared_symbol():
     names = declared("lghip_comm.h")
     assert sorted(hiplib.COMM_PROTOTYPES) == names

@@ -52,18 +52,24 @@ def parse():
                     help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
                     help="graph: the step's kernels are captured once in hipGraphs and replayed; eager: python tape every step")
-    ap.add_argument("--comm-dispatch", choices=["auto", "graph", "graph-inline", "eager"], default="auto",
-                    help="N > 1, where the gradient all-reduce runs: graph = a forked branch INSIDE the captured step, overlapped "
-                         "with the input-gradient GEMM (no host call per step); graph-inline = inside the captured step on the "
-                         "compute stream (no branch, no overlap); eager = forward+backward replay from a graph, all-reduce and "
-                         "optimizer are host calls; auto = time a short run of each and keep the fastest (all ranks agree)")
+    ap.add_argument("--comm-dispatch", choices=["auto", "p2p", "graph", "graph-inline", "eager"], default="auto",
+                    help="N > 1, how the gradients are exchanged: p2p = hand-written exchange through peer-mapped device memory INSIDE "
+                         "the optimizer launch of the captured step (csrc/p2p.hip: no collective library, no extra launch); graph = RCCL "
+                         "all-reduce as a forked branch inside the captured step, overlapped with the input-gradient GEMM; graph-inline = "
+                         "RCCL all-reduce inside the captured step on the compute stream; eager = forward+backward replay from a graph, "
+                         "RCCL all-reduce and optimizer are host calls; auto = the host-launched RCCL form is timed in full first, then "
+                         "a short run of each other form, fastest kept (all ranks agree)")
+    ap.add_argument("--watchdog-exit-code", type=int, default=3,
+                    help="exit code of a rank whose in-graph exchange did not come back within --exchange-timeout (the JSON line of the "
+                         "host-launched form has been printed by then; the device is not to be trusted afterwards)")
     ap.add_argument("--exchange-timeout", type=float, default=180.0,
                     help="N > 1, --comm-dispatch auto: seconds an in-graph form of the exchange may take (calibration or full run) "
                          "before the result of the host-launched form, measured first, is printed and the job ends")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="N > 1 on a box with ONE GPU: every rank binds device 0 and the collectives are staged through the host "
-                         "(gloo) - a rehearsal of the multi-rank code of this script and of DataParallel, NOT a measurement "
-                         "(RCCL refuses a second rank on a device); the metric name says so")
+                    help="N > 1 on a box with ONE GPU: every rank binds device 0 and the ranks exchange through peer-mapped device "
+                         "memory (RCCL refuses a second rank on a device, hipIpc handles are per process) - the multi-rank code of this "
+                         "script, of DataParallel and of csrc/p2p.hip runs for real, but N ranks sharing one GPU measure no scaling; "
+                         "the metric name says so")
     ap.add_argument("--graph-steps", type=int, default=8,
                     help="training steps recorded per hipGraph (each one complete: forward, backward, exchange, update); a replay "
                          "boundary costs ~8 us of idle GPU, so several steps per graph amortise it.  1 = one step per replay")
@@ -180,22 +186,43 @@ def gpu_rank(args, rank, world):
     import lightgrad_amd as light
     from lightgrad_amd import HipTensor, CpuTensor
     from lightgrad_amd.autograd.hip import HipDevice, HipGraph, lib as L
-    from lightgrad_amd.dist import RcclCommunicator, SingleProcess, DataParallel
+    from lightgrad_amd.dist import RcclCommunicator, PeerWindowCommunicator, SingleProcess, DataParallel
 
     if args.rehearse_on_one_gpu:
-        os.environ["LIGHTGRAD_HIP_DEVICE"] = "0"     # every rank on the one GPU
+        from lightgrad_amd.dist import shared_gpu_environment
+        os.environ.update(shared_gpu_environment(rank, world))      # every rank on the one GPU, each on its own share of the CUs
     lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
     info = HipDevice.info()
     multi = world > 1 or args.force_comm
+    # `comm` carries the bench's own bookkeeping (fences, slowest rank's clock) and the RCCL forms of the exchange; `peer` is
+    # the peer-window communicator of the p2p form.  Ranks that share ONE GPU have only the latter (RCCL refuses a second rank
+    # on a device; hipIpc handles are per process) - and between GPUs the peer windows are an extra that must prove itself:
+    # if a rank cannot map a peer's window, or the self-test against RCCL disagrees, every rank drops the form (`peer_error`).
+    peer, peer_error = None, None
     if args.rehearse_on_one_gpu and world > 1:
-        import torch.distributed as tdist
-        from lightgrad_amd.dist import HostStagedCommunicator, _c_stdout_to_stderr
-        with _c_stdout_to_stderr():                  # gloo prints a banner on stdout; stdout carries the one JSON line
-            tdist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ["MASTER_PORT"]),
-                                     rank=rank, world_size=world)
-        comm = HostStagedCommunicator()
+        comm = peer = PeerWindowCommunicator(rank, world)
+    elif multi:
+        comm = RcclCommunicator(rank, world)
+        if args.comm_dispatch in ("auto", "p2p"):
+            try:
+                peer = PeerWindowCommunicator(rank, world)
+                probe = np.random.RandomState(4242 + rank).uniform(-1, 1, 70001).astype(np.float32)
+                via_peer, via_rccl = HipTensor.from_numpy(probe, requires_grad=False), HipTensor.from_numpy(probe, requires_grad=False)
+                peer.allreduce_sum_(via_peer)
+                comm.allreduce_sum_(via_rccl)
+                np.testing.assert_allclose(via_peer.numpy(), via_rccl.numpy(), rtol=1e-5, atol=1e-6)
+            except (L.HipError, AssertionError, TimeoutError, OSError) as e:
+                peer_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            agree = HipTensor.from_numpy(np.asarray([0.0 if peer_error is None else 1.0], np.float32), requires_grad=False)
+            comm.allreduce_max_(agree)
+            if agree.numpy()[0] != 0.0:
+                peer_error = peer_error or "another rank could not set the peer windows up"
+                sys.stderr.write("[bench] rank %d: no peer-window exchange (%s)\n" % (rank, peer_error))
+                peer = None
+            if peer is None and args.comm_dispatch == "p2p":
+                raise L.HipError("--comm-dispatch p2p: " + peer_error)
     else:
-        comm = RcclCommunicator(rank, world) if multi else SingleProcess()
+        comm = SingleProcess()
     # rocprofv3 (ROCm 7.2) faults in its HSA queue interceptor when a hipGraph's packet batch crosses the end of the
     # 16384-packet AQL ring (profiles/README.md, r2): keep the number of replayed graph nodes small when it is attached
     under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
@@ -242,13 +269,15 @@ def gpu_rank(args, rank, world):
         w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
         model.map_parameters(lambda p: p.hip())
         use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
-        overlap = multi and (comm_dispatch == "graph" or not use_graph)
-        dp = DataParallel(model.parameters(), comm, flatten=use_graph, overlap=overlap)
+        in_optimizer = multi and comm_dispatch == "p2p" and use_graph      # exchange inside the optimizer launch (csrc/p2p.hip)
+        leg_comm = peer if (comm_dispatch == "p2p" or comm is peer) else comm
+        overlap = multi and not in_optimizer and leg_comm is not peer and (comm_dispatch == "graph" or not use_graph)
+        dp = DataParallel(model.parameters(), leg_comm, flatten=use_graph, overlap=overlap)
         dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
         opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
                                     device_step=use_graph)
         if use_graph:
-            dp.attach(opt)                               # flat buckets: zero_grad = one flag, update = one launch
+            dp.attach(opt, exchange_in_optimizer=in_optimizer)        # flat buckets: zero_grad = one flag, update = one launch
         rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
         x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
         x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
@@ -278,7 +307,7 @@ def gpu_rank(args, rank, world):
         if use_graph:
             n_params = len(opt.parameters)
             g_all = None
-            if not multi or comm_dispatch in ("graph", "graph-inline"):
+            if not multi or comm_dispatch in ("p2p", "graph", "graph-inline"):
                 # ONE graph for the whole step.  With a communicator the all-reduce is part of it - as a forked branch (started on
                 # the communication stream after the last parameter-gradient kernel, joined before the optimizer kernel) or, with
                 # graph-inline, as one more node of the chain on the compute stream.
@@ -395,13 +424,18 @@ def gpu_rank(args, rank, world):
 
     def assemble(R, chosen, calibration, fallback_reason, extra):
         """the one JSON line for a finished leg"""
+        exchange_comm = peer if (chosen == "p2p" or comm is peer) else comm
         ranks_info = {"world_size": world, "communicator": type(comm).__name__,
-                      "communicator_ranks": (comm.ranks_seen() if hasattr(comm, "ranks_seen") else comm.world_size) if multi else 1,   # lg_comm_rank: what RCCL itself reports
+                      "exchange_communicator": type(exchange_comm).__name__ if multi else None,
+                      "peer_window_exchange": None if not multi else ("available" if peer is not None else "not available: %s" % peer_error),
+                      "communicator_ranks": (exchange_comm.ranks_seen() if hasattr(exchange_comm, "ranks_seen") else exchange_comm.world_size) if multi else 1,   # what the library itself reports
                       "per_rank_steps_per_sec": [round(v, 2) for v in R["per_rank"]],
                       "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else
                                   ("torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else "none"),
                       "exchange": None if not multi else
-                                  {"graph": "all-reduce forked inside the captured step, overlapped with the input-gradient GEMM",
+                                  {"p2p": "hand-written exchange through peer-mapped device memory inside the optimizer launch of the captured step "
+                                          "(push to the chunk owner, sum in rank order, publish; no collective library, no extra launch)",
+                                   "graph": "all-reduce forked inside the captured step, overlapped with the input-gradient GEMM",
                                    "graph-inline": "all-reduce inside the captured step on the compute stream (no branch, no overlap)",
                                    "eager": "host-launched all-reduce after the replayed forward+backward graph"}.get(chosen, chosen)
                                   if R["use_graph"] else "host-launched all-reduce on the communication stream, overlapped with backward (eager tape)",
@@ -409,7 +443,7 @@ def gpu_rank(args, rank, world):
                       "exchange_calibration_steps_per_sec": calibration or None,
                       "in_graph_exchange_fallback": fallback_reason}
         out = {
-            "metric": ("REHEARSAL_ranks_share_one_gpu_host_staged_collectives__" if args.rehearse_on_one_gpu else "") +
+            "metric": ("REHEARSAL_ranks_share_one_gpu__" if args.rehearse_on_one_gpu else "") +
                       "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": round(R["steps_per_s"], 2), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * R["elapsed"] / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -462,7 +496,7 @@ def gpu_rank(args, rank, world):
                         print(state["line"])
                         sys.stdout.flush()
                     sys.stderr.flush()
-                    os._exit(0)                      # the stuck collective cannot be recovered in this process
+                    os._exit(args.watchdog_exit_code)   # the stuck collective cannot be recovered in this process: not a success
         threading.Thread(target=watchdog, daemon=True).start()
 
         def guarded(mode, what, fn):
@@ -475,7 +509,8 @@ def gpu_rank(args, rank, world):
             finally:
                 state["deadline"] = None
 
-        for mode in ("graph-inline", "graph"):
+        # the peer-window form first (the cheapest exchange); the forked RCCL branch does not exist for ranks that share a GPU
+        for mode in (["p2p"] if peer is not None else []) + ["graph-inline"] + (["graph"] if comm is not peer else []):
             try:
                 quick_steps = 5 * args.graph_steps
                 if os.environ.get("LG_BENCH_SIMULATE_HANG") == mode:          # tests of the watchdog only
@@ -496,7 +531,7 @@ def gpu_rank(args, rank, world):
                     sys.stderr.write("[bench] rank %d: the full run with exchange form %r failed (%s)\n" % (rank, mode, fallback_reason))
         out = assemble(best, chosen, calibration, fallback_reason, extra)
     else:
-        modes = ["graph", "eager"] if (multi and args.comm_dispatch == "graph") else [args.comm_dispatch if multi else "graph"]
+        modes = {"graph": ["graph", "eager"], "p2p": ["p2p", "eager"]}.get(args.comm_dispatch, [args.comm_dispatch]) if multi else ["graph"]
         R, chosen = None, None
         for k, mode in enumerate(modes):
             try:
@@ -511,6 +546,8 @@ def gpu_rank(args, rank, world):
                                  % (rank, mode, fallback_reason, modes[k + 1]))
         out = assemble(R, chosen, calibration, fallback_reason, side_measurements(R))
     if multi:
+        if peer is not None and peer is not comm:
+            peer.close()
         comm.close()
     if rank == 0:
         print(json.dumps(out))

@@ -20,6 +20,10 @@
  * lg_p2p_adam_multi_dev_f32 is lg_adam_multi_dev_f32 (lghip.h) with this exchange in front of the update, in the SAME
  * launch: the data-parallel training step keeps the launch count of the single-GPU step.
  *
+ * One rank per GPU is the deployment.  Rank processes that share ONE GPU (how this path is tested on one-GPU machines:
+ * hipIpc handles are per process, not per device) must each be confined to CUs of their own - LG_CU_MASK=<k>/<n> in the
+ * environment before lg_init - or a rank's waiting workgroups can keep its peer's kernels off the device.
+ *
  * Rendezvous: lg_p2p_export gives 64 bytes that the launcher's rendezvous files carry to the peers (like the RCCL id of
  * lghip_comm.h); lg_p2p_connect takes all ranks' handles.  All functions return 0 or a negative LG_E* code (lghip.h)
  * with the message in lg_last_error(); launches go to the compute stream (lg_stream()).

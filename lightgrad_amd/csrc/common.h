@@ -52,6 +52,9 @@ bool gemm_group_is_open();
 int gemm_group_flush_pending();
 int ln_group_flush_pending();
 
+// p2p.hip: what the first wait of the peer-window exchange that gave up was waiting for
+void p2p_describe_timeout(char* out, size_t len);
+
 // main stream waits for the side stream, blocks freed meanwhile return to the pool (no-op when nothing is pending)
 int side_join();
 

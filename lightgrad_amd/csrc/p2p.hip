@@ -19,8 +19,12 @@
 // after every rank has finished reading "reduced" of e.
 //
 // Deadlock freedom: workgroup c of a rank waits only for workgroup c of other ranks, and pushes before it waits.  The
-// host keeps a launch at <= kMaxChunksPerLaunch workgroups (all resident at once, also with two ranks on one GPU) by
-// giving a workgroup several 1024-float pieces.
+// host keeps a launch at <= kMaxChunksPerLaunch workgroups (all resident at once) by giving a workgroup several
+// 1024-float pieces.  One rank per GPU: while a rank's exchange launch waits, nothing else of that rank needs the device
+// (its stream is serial).  Rank processes that SHARE a GPU must each run on CUs of their own (LG_CU_MASK, runtime.hip):
+// measured on MI355X, a rank's waiting workgroups spread over all CUs can keep the OTHER rank's kernels - the very ones
+// that lead to the launch being waited for - off the device (tests/test_hip_dist.py at MNIST-MLP size: 3 of 3 runs stuck
+// until the wait gave up without the masks, 0 of 7 with them).
 #include "common.h"
 #include "adam_common.h"
 #include "../../include/lghip_p2p.h"
@@ -43,7 +47,7 @@ struct P2PCtx {
     float*  reduced[LG_P2P_MAX_RANKS];
     int*    flag1[LG_P2P_MAX_RANKS];
     int*    flag2[LG_P2P_MAX_RANKS];
-    int*    local;                               // this rank only: [0] epoch, [1] dead, [32 ...] arrival tickets
+    int*    local;                               // this rank only: [0] epoch, [1] dead, [2..6] timeout record, [32 ...] arrival tickets
     int*    status;                              // device status flag (runtime.hip)
     int64_t spin_ticks;                          // a wait gives up after this many ticks of wall_clock64 (100 MHz)
 };
@@ -51,8 +55,10 @@ struct P2PCtx {
 __device__ __forceinline__ void st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ int  ld_sys(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// wait until *flag has reached epoch `want`; gives up after x.spin_ticks (or at once when an earlier wait gave up)
-__device__ __forceinline__ void spin_ge(const int* flag, int want, const P2PCtx& x) {
+// wait until *flag has reached epoch `want`; gives up after x.spin_ticks (or at once when an earlier wait gave up).
+// The FIRST wait that gives up leaves a record for the error message: local[2..6] = chunk, epoch wanted, value seen,
+// kind (1 = a peer's push, 2 = the owner's sum), the rank waited for.
+__device__ __forceinline__ void spin_ge(const int* flag, int want, const P2PCtx& x, int chunk, int kind, int from) {
     if (ld_sys(flag) - want >= 0) return;
     const int64_t t0 = wall_clock64();
     for (int n = 1;; ++n) {
@@ -61,7 +67,9 @@ __device__ __forceinline__ void spin_ge(const int* flag, int want, const P2PCtx&
         if ((n & 31) == 0) {
             if (__hip_atomic_load(x.local + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
             if (wall_clock64() - t0 > x.spin_ticks) {
-                __hip_atomic_store(x.local + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(x.local + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    x.local[2] = chunk; x.local[3] = want; x.local[4] = ld_sys(flag); x.local[5] = kind; x.local[6] = from;
+                }
                 __hip_atomic_fetch_or(x.status, LG_STATUS_P2P_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
@@ -119,9 +127,12 @@ __device__ __forceinline__ void local_store(float* p, int nvalid, bool vec, cons
 
 // The exchange of ONE chunk by ONE workgroup (all 256 threads call it).  The chunk is `pieces` pieces of 1024 floats
 // starting at element `first` of the bucket `g` (bucket-absolute = slot-relative index), of which elements < `end`
-// exist.  On return g[first .. end) holds the reduced values on every rank (the owner's bits).
+// exist.  On return g[first .. end) holds the reduced values on every rank (the owner's bits), and `last` this thread's
+// four reduced values of the chunk's LAST piece (the only one in small launches): a caller that goes on computing with
+// them need not wait for its own stores to g.
 template <bool kMax>
-__device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int chunk, float* g, int64_t first, int64_t end, int pieces, bool vec) {
+__device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int chunk, float* g, int64_t first, int64_t end, int pieces, bool vec,
+                                               float (&last)[4]) {
     const int tid = threadIdx.x, me = x.rank, n = x.nranks, owner = chunk % n;
     if (owner != me) {
         float* slot = x.recv[owner] + int64_t(me) * x.cap;
@@ -138,7 +149,7 @@ __device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int c
         __syncthreads();
         if (tid == 0) {
             st_sys(x.flag1[owner] + int64_t(chunk) * kFlag1Stride + me, epoch);
-            spin_ge(x.flag2[me] + chunk, epoch, x);
+            spin_ge(x.flag2[me] + chunk, epoch, x, chunk, 2, owner);
         }
         __syncthreads();
         for (int q = 0; q < pieces; ++q) {
@@ -148,11 +159,15 @@ __device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int c
                 float v[4];
                 slot_load(x.reduced[me], x.cap, elem, nvalid, vec, v);
                 local_store(g + elem, nvalid, vec, v);
+                if (q == pieces - 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) last[e] = v[e];
+                }
             }
         }
         return;
     }
-    if (tid < n && tid != me) spin_ge(x.flag1[me] + int64_t(chunk) * kFlag1Stride + tid, epoch, x);
+    if (tid < n && tid != me) spin_ge(x.flag1[me] + int64_t(chunk) * kFlag1Stride + tid, epoch, x, chunk, 1, tid);
     __syncthreads();
     for (int q = 0; q < pieces; ++q) {
         const int64_t elem = first + int64_t(q) * kPiece + tid * 4;
@@ -175,6 +190,10 @@ __device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int c
                     for (int e = 0; e < 4; ++e) v[e] = kMax ? fmaxf(v[e], part[r][e]) : v[e] + part[r][e];
                 }
             local_store(g + elem, nvalid, vec, v);
+            if (q == pieces - 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) last[e] = v[e];
+            }
 #pragma unroll
             for (int r = 0; r < LG_P2P_MAX_RANKS; ++r)
                 if (r < n && r != me) slot_store(x.reduced[r], x.cap, elem, nvalid, vec, v);
@@ -207,10 +226,11 @@ __device__ __forceinline__ void arrive(const P2PCtx& x, int a, int total, int ep
 
 template <bool kMax>
 __global__ void __launch_bounds__(256) p2p_allreduce(P2PCtx x, float* buf, int64_t n, int pieces, int vec) {
-    const int epoch = x.local[0] + 1;
+    const int epoch = __hip_atomic_load(x.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const int c = blockIdx.x;
     const int64_t first = int64_t(c) * pieces * kPiece;
-    exchange_chunk<kMax>(x, epoch, c, buf, first, n, pieces, vec != 0);
+    float last[4];
+    exchange_chunk<kMax>(x, epoch, c, buf, first, n, pieces, vec != 0, last);
     arrive(x, c, gridDim.x, epoch, nullptr);
 }
 
@@ -232,15 +252,16 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
     const int64_t begin = seg.offsets[j], end = seg.offsets[j + 1];
     const int64_t first = begin + int64_t(blockIdx.x) * seg.pieces * kPiece;
     if (first >= end) return;                                      // workgroup-uniform; such workgroups take no ticket
-    const int epoch = x.local[0] + 1;
+    const int epoch = __hip_atomic_load(x.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     if (threadIdx.x == 0) {
-        const double t = double(step[0] * seg.nseg_total + seg.first + j + 1);
+        const double t = double(__hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * seg.nseg_total + seg.first + j + 1);
         inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
         inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
     }
     const bool vec = base_aligned && (begin & 3) == 0;
     const int chunk = seg.chunk_base[j] + blockIdx.x;
-    exchange_chunk<false>(x, epoch, chunk, g, first, end, seg.pieces, vec);       // barriers inside: inv_bias is visible after it
+    float last[4] = {0.f, 0.f, 0.f, 0.f};
+    exchange_chunk<false>(x, epoch, chunk, g, first, end, seg.pieces, vec, last);       // barriers inside: inv_bias is visible after it
     c.inv_bias1 = inv_bias[0];
     c.inv_bias2 = inv_bias[1];
     for (int q = 0; q < seg.pieces; ++q) {
@@ -248,7 +269,12 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
         const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
         if (nvalid > 0) {
             float G[4], P[4], M[4], V[4];
-            local_load(g + elem, nvalid, vec, G);                  // this thread's own stores of the reduced values
+            if (q == seg.pieces - 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) G[e] = last[e];
+            } else {
+                local_load(g + elem, nvalid, vec, G);              // this thread's own stores of the reduced values
+            }
             local_load(p + elem, nvalid, vec, P);
             local_load(m + elem, nvalid, vec, M);
             local_load(v + elem, nvalid, vec, V);
@@ -301,6 +327,19 @@ static P2PCtx make_ctx() {
     x.status = rt().status_dev;
     x.spin_ticks = S.spin_ticks;
     return x;
+}
+
+// for the error text of a wait that gave up (runtime.hip: check_device_status, after the stream has been synchronised)
+void p2p_describe_timeout(char* out, size_t len) {
+    P2PState& S = st();
+    int rec[8] = {};
+    if (!S.local || hipMemcpy(rec, S.local, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(out, len, "no record");
+        return;
+    }
+    snprintf(out, len, "rank %d of %d, at launch epoch %d: chunk %d waited for %s rank %d to reach epoch %d and saw %d", S.rank, S.nranks, rec[0],
+             rec[2], rec[5] == 1 ? "the push of" : "the sum from", rec[6], rec[3], rec[4]);
 }
 
 }  // namespace lg

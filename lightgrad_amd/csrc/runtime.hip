@@ -72,8 +72,10 @@ int check_device_status(const char* who) {
     const int status = __atomic_exchange_n(R.status_host, 0, __ATOMIC_ACQ_REL);
     if (status == 0) return LG_OK;
     if (status & LG_STATUS_P2P_TIMEOUT) {
-        set_error("%s: a peer-window exchange launched earlier waited more than %d s for another rank (lghip_p2p.h); the gradient "
-                  "buckets and parameters of this rank are not to be trusted (device status %d)", who, LG_P2P_TIMEOUT_S, status);
+        char what[256];
+        p2p_describe_timeout(what, sizeof(what));
+        set_error("%s: a peer-window exchange launched earlier gave up waiting for another rank (lghip_p2p.h; %s); the gradient "
+                  "buckets and parameters of this rank are not to be trusted (device status %d)", who, what, status);
         return LG_ECOMM;
     }
     set_error("%s: a kernel launched earlier met an index or label outside its axis (device status %d); results of that "
@@ -138,7 +140,24 @@ int lg_init(int device) {
     LG_HIP(hipGetDeviceCount(&n));
     LG_ARG(device >= 0 && device < n, "lg_init: device %d out of range (%d visible)", device, n);
     LG_HIP(hipSetDevice(device));
-    LG_HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+    // LG_CU_MASK=<k>/<n>: the compute stream runs on part k of n equal parts of the CUs.  For rank processes that SHARE a GPU
+    // (tests and rehearsals of the data-parallel path on a one-GPU box): each rank then owns its CUs like a GPU of its own,
+    // and a kernel of one rank that waits for another (csrc/p2p.hip) can never keep that rank's kernels off the device.
+    int part = -1, parts = 0;
+    if (const char* spec = getenv("LG_CU_MASK")) {
+        LG_ARG(sscanf(spec, "%d/%d", &part, &parts) == 2 && parts >= 1 && part >= 0 && part < parts, "lg_init: LG_CU_MASK=%s is not <k>/<n> with 0 <= k < n", spec);
+    }
+    if (parts > 1) {
+        hipDeviceProp_t prop0;
+        LG_HIP(hipGetDeviceProperties(&prop0, device));
+        const int cus = prop0.multiProcessorCount, words = (cus + 31) / 32;
+        LG_ARG(parts <= cus, "lg_init: LG_CU_MASK asks for %d parts of %d CUs", parts, cus);
+        std::vector<uint32_t> mask(words, 0u);
+        for (int cu = part * cus / parts; cu < (part + 1) * cus / parts; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+        LG_HIP(hipExtStreamCreateWithCUMask(&R.stream, uint32_t(words), mask.data()));
+    } else {
+        LG_HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+    }
     R.main_stream = R.stream;
     {
         int least = 0, greatest = 0;                      // numerically greatest = lowest priority: the main chain wins contended CUs

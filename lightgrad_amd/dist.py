@@ -287,21 +287,42 @@ class PeerWindowCommunicator(Communicator):
     DataParallel.attach hands the optimizer this communicator, sync_gradients() then launches nothing).
 
     Works over xGMI between the GPUs of a node and between rank processes that SHARE one GPU (hipIpc handles are per
-    process, not per device) - which is how the multi-rank device path is tested on one-GPU machines."""
+    process, not per device) - which is how the multi-rank device path is tested on one-GPU machines; ranks that share a
+    GPU must each run on CUs of their own (`shared_gpu_environment`)."""
     fused_optimizer_exchange = True
 
-    def __init__(self, rank=None, world_size=None, id_path=None, capacity_floats=1 << 22):
+    def __init__(self, rank=None, world_size=None, id_path=None, capacity_floats=1 << 22, rendezvous_timeout=120.0):
         from .autograd.hip import lib as L
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
         self._L, self._lib = L, L.lib()
         self._prefix = (_job_rendezvous_path() if id_path is None else id_path) + ".p2p"
+        self._open = False
         handle = ctypes.create_string_buffer(L.P2P_HANDLE_BYTES)
-        L.check(self._lib.lg_p2p_export(self.rank, self.world_size, int(capacity_floats), handle))
+        rc = self._lib.lg_p2p_export(self.rank, self.world_size, int(capacity_floats), handle)
+        export_error = None if rc == 0 else self._lib.lg_last_error().decode()
+        # a rank that could not export still publishes (64 zero bytes): its peers fail at once instead of waiting for it
+        blobs = _exchange_blobs(self.rank, self.world_size, handle.raw if rc == 0 else bytes(L.P2P_HANDLE_BYTES), self._prefix,
+                                timeout=rendezvous_timeout)
+        failed = [r for r, b in enumerate(blobs) if not any(b)]
+        if failed:
+            if rc == 0:
+                self._lib.lg_p2p_free()
+            raise L.HipError("peer-window exchange: rank(s) %s could not export a window%s" % (failed, ": " + export_error if export_error else ""))
         self._open = True
-        blobs = _exchange_blobs(self.rank, self.world_size, handle.raw, self._prefix)
-        L.check(self._lib.lg_p2p_connect(ctypes.create_string_buffer(b"".join(blobs), len(blobs) * L.P2P_HANDLE_BYTES)))
-        self.barrier()                  # every rank has mapped every window ...
+        try:
+            L.check(self._lib.lg_p2p_connect(ctypes.create_string_buffer(b"".join(blobs), len(blobs) * L.P2P_HANDLE_BYTES)))
+        except L.HipError:
+            self._open = False
+            self._lib.lg_p2p_free()
+            raise
+        try:
+            self.barrier()              # every rank has mapped every window ...
+        except L.HipError:              # ... or one could not, and this rank's wait for it gave up (lghip_p2p.h: LG_P2P_TIMEOUT_S)
+            self._open = False
+            self._lib.lg_p2p_disconnect()
+            self._lib.lg_p2p_free()
+            raise
         try:
             os.remove("%s.%d" % (self._prefix, self.rank))       # ... so nobody reads this file any more
         except OSError:
@@ -351,6 +372,13 @@ class PeerWindowCommunicator(Communicator):
         # own could be gone before a slower peer has read it; lightgrad_amd.launch clears the job's directory)
         _exchange_blobs(self.rank, self.world_size, b"bye", self._prefix + ".bye")
         self._L.check(self._lib.lg_p2p_free())
+
+
+def shared_gpu_environment(rank: int, world_size: int) -> dict:
+    """environment of a rank process that shares ONE GPU with the other ranks of its job (tests, rehearsals): every rank
+    binds device 0 and is confined to its own 1/world_size of the CUs (csrc/runtime.hip, LG_CU_MASK) - a rank whose exchange
+    kernel waits for a peer then cannot keep that peer's kernels off the device.  Set before the library initialises."""
+    return {"LIGHTGRAD_HIP_DEVICE": "0", "LG_CU_MASK": "%d/%d" % (rank, world_size)}
 
 
 def _flat_and_views(cls, shapes):
@@ -448,12 +476,17 @@ class DataParallel(object):
         """forget the learnt write count (the next step exchanges after backward and learns again)"""
         self._writes_expected, self._writes_seen, self._exchange_started = None, 0, False
 
-    def attach(self, optimizer):
-        """hand the flat buckets to an optimizer that can use them (one fill for zero_grad, one launch for step)"""
+    def attach(self, optimizer, exchange_in_optimizer=None):
+        """hand the flat buckets to an optimizer that can use them (one fill for zero_grad, one launch for step).
+        exchange_in_optimizer: None = whenever the communicator offers it, False = keep the exchange in sync_gradients()"""
         assert self.flat_parameters is not None, "DataParallel(..., flatten=True) first"
         assert tuple(optimizer.parameters) == self.parameters
         optimizer.use_flat_buckets(self.flat_parameters, self.bucket, self.offsets)
-        if getattr(self.comm, "fused_optimizer_exchange", False) and self._exchange_needed():
+        if exchange_in_optimizer is None:
+            exchange_in_optimizer = getattr(self.comm, "fused_optimizer_exchange", False)
+        assert not exchange_in_optimizer or getattr(self.comm, "fused_optimizer_exchange", False), \
+            "%s cannot exchange inside the optimizer launch" % type(self.comm).__name__
+        if exchange_in_optimizer and self._exchange_needed():
             # the gradient exchange happens INSIDE the optimizer's launch (lg_p2p_adam_multi_dev_f32): nothing to overlap,
             # nothing for sync_gradients() to launch
             optimizer.use_peer_exchange(self.comm)

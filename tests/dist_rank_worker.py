@@ -18,12 +18,23 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
-os.environ["LIGHTGRAD_HIP_DEVICE"] = "0"          # every rank on the one GPU
+os.environ["LIGHTGRAD_HIP_DEVICE"] = "0"          # every rank on the one GPU ...
+if os.environ.get("LIGHTGRAD_WORKER_MASK", "1") == "1":  # ... each on its own share of the CUs (dist.shared_gpu_environment)
+    os.environ["LG_CU_MASK"] = "%s/%s" % (os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"))
 
 import faulthandler  # noqa: E402
 import numpy as np  # noqa: E402
 
 faulthandler.dump_traceback_later(int(os.environ.get("LIGHTGRAD_WORKER_DUMP_AFTER", "100")), exit=False)   # a stuck rank says where
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    if os.environ.get("LIGHTGRAD_WORKER_VERBOSE"):
+        sys.stderr.write("[rank %s %7.3f s] %s\n" % (os.environ.get("RANK"), time.time() - _T0, msg))
+        sys.stderr.flush()
 
 
 def make_comm(kind, rank, world):
@@ -33,7 +44,8 @@ def make_comm(kind, rank, world):
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
         return HostStagedCommunicator()
     from lightgrad_amd.dist import PeerWindowCommunicator
-    return PeerWindowCommunicator(rank, world, capacity_floats=1 << 16)     # small window: large buffers take several launches
+    # a small window by default: large buffers then take several launches
+    return PeerWindowCommunicator(rank, world, capacity_floats=int(os.environ.get("LIGHTGRAD_TEST_WINDOW_FLOATS", 1 << 16)))
 
 
 def train(args, rank, world):
@@ -44,15 +56,18 @@ def train(args, rank, world):
     from test_cpu_backend import MLP
     import np_oracle as O
     comm = make_comm(args.comm, rank, world)
+    log("communicator up")
     np.random.seed(100 + rank)                     # deliberately different init per rank: broadcast must fix it
-    model = MLP(20, 16, 10).map_parameters(lambda p: p.hip())
+    d_in, d_hidden, d_out = args.dims
+    model = MLP(d_in, d_hidden, d_out).map_parameters(lambda p: p.hip())
     dp = DataParallel(model.parameters(), comm, flatten=args.fused, overlap=args.overlap)
     w_start = {n: p.numpy().copy() for n, p in model.named_parameters()}
     opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, eps=0.05, grad_scale=dp.grad_scale, fused=args.fused, device_step=args.fused)
     if args.fused:
         dp.attach(opt)                             # flat buckets; with the peer-window communicator: exchange inside the optimizer launch
     in_optimizer = dp._exchange_in_optimizer
-    _, x, onehot, _ = O.synthetic_mlp_problem(500 + rank, 20, 16, 10, 8)     # own batch per rank
+    log("model, bucket, optimizer ready")
+    _, x, onehot, _ = O.synthetic_mlp_problem(500 + rank, d_in, d_hidden, d_out, args.batch)     # own batch per rank
     xt, tt = HipTensor.from_numpy(x), HipTensor.from_numpy(onehot)
 
     def step():
@@ -60,13 +75,16 @@ def train(args, rank, world):
         opt.zero_grad()
         l.backward()
         dp.sync_gradients()
+        log("backward launched")
         g = None if in_optimizer else {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
         opt.step()
+        log("optimizer launched")
         if in_optimizer:                           # the bucket holds the summed gradient once the optimizer launch has run
             g = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
         return l, g
     losses = []
     l, g_sum = step()
+    log("first step launched and read back")
     losses.append(l.item())
     w_after_first = {n: p.numpy().copy() for n, p in model.named_parameters()}
     if args.graph:
@@ -175,6 +193,16 @@ if __name__ == "__main__":
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--out", default=".")
+    ap.add_argument("--dims", default="20,16,10", help="MLP sizes: inputs,hidden,outputs")
+    ap.add_argument("--batch", type=int, default=8)
     a = ap.parse_args()
     a.overlap, a.fused, a.graph = bool(a.overlap), bool(a.fused), bool(a.graph)
-    {"train": train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+    a.dims = tuple(int(v) for v in a.dims.split(","))
+    try:
+        {"train": train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        time.sleep(float(os.environ.get("LIGHTGRAD_WORKER_LINGER", "0")))      # debugging: let the other rank report too before the job is stopped
+        sys.exit(1)

@@ -89,6 +89,25 @@ def test_exchange_in_graph_equals_eager(spawn_ranks, tmp_path):
                 np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_exchange_at_mnist_mlp_size_in_a_replayed_graph(spawn_ranks, tmp_path):
+    """BASELINE config #4 at its real size (784 -> 512 -> 10, batch 1024 per rank: 399 exchange workgroups per launch), 200 steps
+    replayed from a hipGraph with both ranks on one GPU.  This is the case that needs each rank on CUs of its own
+    (dist.shared_gpu_environment): without the masks the waiting workgroups of one rank keep the other's kernels off the device."""
+    _run(spawn_ranks, tmp_path, "--comm", "p2p", "--fused", 1, "--graph", 1, "--steps", 200, "--dims", "784,512,10", "--batch", 1024,
+         env={"LIGHTGRAD_TEST_WINDOW_FLOATS": 1 << 22})
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        if k.startswith(("w0/", "g/", "w1/", "wf/")):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    assert np.all(np.isfinite(r0["losses"])) and r0["losses"][-1] < r0["losses"][0]
+    import np_oracle as O
+    w0 = {n: r0["w0/" + n] for n in O.PARAM_ORDER}
+    _, g_cat, _ = O.mlp_loss_and_grads(w0, np.concatenate([r0["x"], r1["x"]]), np.concatenate([r0["onehot"], r1["onehot"]]))
+    for n in O.PARAM_ORDER:           # SUM over the ranks == gradient of the concatenated 2048-sample batch
+        scale = np.abs(g_cat[n]).max()
+        np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * scale, err_msg=n)
+
+
 def test_peer_window_collectives(spawn_ranks, tmp_path):
     res = _run(spawn_ranks, tmp_path, "--mode", "collectives")
     assert all("collectives ok" in o for o in res["outputs"]), res["outputs"]

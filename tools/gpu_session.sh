@@ -10,6 +10,6 @@ while IFS='|' read -r name secs cmd; do
   rc=$?
   echo "=== $name rc=$rc after $(( $(date +%s) - start ))s"
   tail -c 1500 "$out/$name.out"; tail -c 600 "$out/$name.err"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "step $name was killed at its limit: stopping the session"; exit $rc; fi
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ] || [ $rc -eq 3 ]; then echo "step $name was killed at its limit or reported a hung exchange (rc $rc): stopping the session"; exit $rc; fi
 done
 exit 0

@@ -12,9 +12,9 @@
  *   reduce   the owner waits for the nranks-1 flags of the chunk, adds the contributions IN RANK ORDER, stores the
  *            sum into every peer's window and raises the peers' "reduced" flag of the chunk
  *   consume  a non-owner waits for that flag and reads the sum from its own window
- * so every rank ends with the SAME bits (the owner's sum), the same in every run.  Flags carry a launch epoch kept in
- * device memory (the last workgroup to finish advances it), so a launch recorded in a hipGraph replays correctly, and no
- * flag is ever reset.  A wait gives up after LG_P2P_TIMEOUT_S seconds (a lost peer): the device status flag is raised
+ * so every rank ends with the SAME bits (the owner's sum), the same in every run.  A flag carries the number of exchanges
+ * its chunk has been through; each workgroup keeps that count for its chunk in device memory, so a launch recorded in a
+ * hipGraph replays correctly, no flag is ever reset and no workgroup waits for another one of its own launch.  A wait gives up after LG_P2P_TIMEOUT_S seconds (a lost peer): the device status flag is raised
  * and the next synchronising call of lghip.h returns LG_ECOMM.
  *
  * lg_p2p_adam_multi_dev_f32 is lg_adam_multi_dev_f32 (lghip.h) with this exchange in front of the update, in the SAME
@@ -52,10 +52,13 @@ int lg_p2p_rank(int* rank, int* nranks, int64_t* capacity_floats);
  * every rank must issue the same sequence of lg_p2p_* launches with the same sizes. */
 int lg_p2p_allreduce_f32(float* buf, int64_t n, int op);
 /* lg_adam_multi_dev_f32 with the all-reduce (SUM) of g in front of the update, in the same launch; g holds the summed
- * gradient afterwards.  advance != 0: the launch also adds 1 to step[0] (sharded arrival tickets, no extra launch). */
+ * gradient afterwards.  The launch also advances the optimizer's step number, without any cross-workgroup hand-off:
+ * `step` points to 2 + step_slots int64, all holding the number of steps done so far (zeros for a new optimizer);
+ * step[2 + c] is the private copy of the workgroup of chunk c, step[0] the copy the caller reads.  step_slots >= the
+ * number of 1024-float chunks of the bucket, each segment rounded up: sum over segments of ceil(length / 1024). */
 int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v, int nseg, const int64_t* offsets,
-                              double lr, double b1, double b2, double eps, int64_t* step, double gscale,
-                              int belief, int advance);
+                              double lr, double b1, double b2, double eps, int64_t* step, int64_t step_slots, double gscale,
+                              int belief);
 /* unmap the peers' windows (call on every rank, then synchronise the ranks, then lg_p2p_free) */
 int lg_p2p_disconnect(void);
 int lg_p2p_free(void);

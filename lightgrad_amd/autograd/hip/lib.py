@@ -127,7 +127,7 @@ P2P_PROTOTYPES = {
     "lg_p2p_rank": (c_int, [POINTER(c_int), POINTER(c_int), _I64P]),
     "lg_p2p_allreduce_f32": (c_int, [c_void_p, c_int64, c_int]),
     "lg_p2p_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
-                                          c_double, c_void_p, c_double, c_int, c_int]),
+                                          c_double, c_void_p, c_int64, c_double, c_int]),
     "lg_p2p_disconnect": (c_int, []),
     "lg_p2p_free": (c_int, []),
 }

@@ -630,7 +630,8 @@ class HipTensor(AbstractTensor):
 
     def _fused_adam_multi_p2p(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
         """`_fused_adam_multi_dev` of a data-parallel rank: the SAME launch first sums `grad` over the ranks through the peer
-        windows (include/lghip_p2p.h) and also advances the step counter (sharded arrival tickets: no carrier needed)"""
+        windows (include/lghip_p2p.h) and also advances the step counter (`_new_step_counter(step, slots=...)`: every
+        workgroup keeps a copy of its own, no carrier kernel needed)"""
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         assert offsets[-1] == self.numel()
@@ -638,12 +639,14 @@ class HipTensor(AbstractTensor):
         flush_lazy_readers(grad)
         self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_p2p_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
-                                                    lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 1))
+                                                    lr, b1, b2, eps, step_counter.ptr, step_counter.numel() - 2, grad_scale,
+                                                    1 if belief else 0))
 
     @staticmethod
-    def _new_step_counter(step: int) -> "HipTensor":
-        """device-resident optimizer step number for graph-captured training steps: int64[2] = (step, arrival ticket)"""
-        return HipTensor.from_numpy(np.asarray([step, 0], dtype=np.int64), requires_grad=False)
+    def _new_step_counter(step: int, slots: int = 0) -> "HipTensor":
+        """device-resident optimizer step number for graph-captured training steps: int64[2] = (step, arrival ticket), plus
+        `slots` private copies of the step for the workgroups of `_fused_adam_multi_p2p`"""
+        return HipTensor.from_numpy(np.asarray([step, 0] + [step] * slots, dtype=np.int64), requires_grad=False)
 
     def _fused_adam_step_dev(self, grad, m, v, lr, b1, b2, eps, step_counter, t_mul, t_add, grad_scale, belief):
         """like `_fused_adam_step`, but t = step_counter * t_mul + t_add is evaluated on the device"""

@@ -13,10 +13,16 @@
 // the workgroup's one flag store; payload loads are `sc0 sc1` after a poll + workgroup barrier
 // (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the hand-off table, at system instead of agent scope).
 //
-// Hazards between launches (no flag is ever reset, epochs only grow): a rank enters epoch e+1 only after its epoch-e
-// launch has finished, i.e. after every owner has read the slots of epoch e (its "reduced" flags say so) - so pushes
-// of e+1 never overtake reads of e; an owner stores "reduced" of e+1 only after EVERY rank has pushed for e+1, i.e.
-// after every rank has finished reading "reduced" of e.
+// Epochs.  A flag holds the number of exchanges its chunk has been through.  Workgroup c keeps that number for chunk c in
+// memory of its own rank (local[kEpochBase + c]: read when it starts, written when it ends - by the same workgroup index in
+// every launch, so there is nothing to agree on inside a launch, no arrival ticket and no "last workgroup").  All ranks
+// issue the same sequence of launches, so chunk c's count is the same everywhere.  The optimizer's step number is kept the
+// same way: step[2 + c] is workgroup c's private copy, workgroup 0 mirrors it into step[0].
+//
+// Hazards between launches (no flag is ever reset, epochs only grow): a rank starts its next launch only after the
+// current one has finished, i.e. after every owner has read the slots of this exchange (its "reduced" flags say so) - so
+// the next pushes never overtake these reads; an owner stores the next "reduced" values of a chunk only after EVERY rank
+// has pushed that chunk again, i.e. after every rank has finished reading the current ones.
 //
 // Deadlock freedom: workgroup c of a rank waits only for workgroup c of other ranks, and pushes before it waits.  The
 // host keeps a launch at <= kMaxChunksPerLaunch workgroups (all resident at once) by giving a workgroup several
@@ -35,7 +41,7 @@ namespace lg {
 constexpr int     kPiece = 1024;                 // floats per piece: one float4 per thread of a 256-thread workgroup
 constexpr int     kMaxChunksPerLaunch = 448;
 constexpr int     kFlag1Stride = 16;             // ints per chunk: one 64-byte line
-constexpr int     kTicketShards = 16, kTicketStride = 32;
+constexpr int     kEpochBase = 32;               // local[kEpochBase + c]: exchanges chunk c has been through
 constexpr int     SC_SYS = 1 | 16;               // sc0 sc1 on the raw buffer builtins
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +53,7 @@ struct P2PCtx {
     float*  reduced[LG_P2P_MAX_RANKS];
     int*    flag1[LG_P2P_MAX_RANKS];
     int*    flag2[LG_P2P_MAX_RANKS];
-    int*    local;                               // this rank only: [0] epoch, [1] dead, [2..6] timeout record, [32 ...] arrival tickets
+    int*    local;                               // this rank only: [1] dead, [2..6] timeout record, [kEpochBase + c] epoch of chunk c
     int*    status;                              // device status flag (runtime.hip)
     int64_t spin_ticks;                          // a wait gives up after this many ticks of wall_clock64 (100 MHz)
 };
@@ -204,34 +210,14 @@ __device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int c
     if (tid < n && tid != me) st_sys(x.flag2[tid] + chunk, epoch);
 }
 
-// The workgroup has finished chunk `a` of `total`: the LAST one of the launch publishes the epoch (and the optimizer's
-// step number).  Arrival tickets are sharded 16 ways (one contended word costs ~11 ns per arrival; MI355X_MICROARCH.md,
-// price list, 'fanin') and zero again when the launch ends.  Every workgroup has read epoch / step before it arrives.
-__device__ __forceinline__ void arrive(const P2PCtx& x, int a, int total, int epoch, int64_t* step) {
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    int* tickets = x.local + 32;
-    const int shard = a % kTicketShards;
-    const int in_shard = (total - shard + kTicketShards - 1) / kTicketShards;
-    int* t = tickets + shard * kTicketStride;
-    if (__hip_atomic_fetch_add(t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != in_shard - 1) return;
-    __hip_atomic_store(t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int shards = total < kTicketShards ? total : kTicketShards;
-    int* top = tickets + kTicketShards * kTicketStride;
-    if (__hip_atomic_fetch_add(top, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != shards - 1) return;
-    __hip_atomic_store(top, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(x.local, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (step) step[0] = step[0] + 1;
-}
-
 template <bool kMax>
 __global__ void __launch_bounds__(256) p2p_allreduce(P2PCtx x, float* buf, int64_t n, int pieces, int vec) {
-    const int epoch = __hip_atomic_load(x.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const int c = blockIdx.x;
+    const int epoch = __hip_atomic_load(x.local + kEpochBase + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const int64_t first = int64_t(c) * pieces * kPiece;
     float last[4];
     exchange_chunk<kMax>(x, epoch, c, buf, first, n, pieces, vec != 0, last);
-    arrive(x, c, gridDim.x, epoch, nullptr);
+    if (threadIdx.x == 0) __hip_atomic_store(x.local + kEpochBase + c, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the optimizer launch with the exchange in front ------------------------------------------------------------------
@@ -245,36 +231,43 @@ struct P2PSegments {
 };
 
 __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                      P2PSegments seg, AdamScalars c, int64_t* __restrict__ step, double b1, double b2,
-                                                      int advance, int base_aligned, P2PCtx x) {
+                                                      P2PSegments seg, AdamScalars c, int64_t* __restrict__ step, int step_slot_base, double b1, double b2,
+                                                      int base_aligned, P2PCtx x) {
     __shared__ float inv_bias[2];
     const int j = blockIdx.y;
     const int64_t begin = seg.offsets[j], end = seg.offsets[j + 1];
     const int64_t first = begin + int64_t(blockIdx.x) * seg.pieces * kPiece;
-    if (first >= end) return;                                      // workgroup-uniform; such workgroups take no ticket
-    const int epoch = __hip_atomic_load(x.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (first >= end) return;                                      // workgroup-uniform
+    const int chunk = seg.chunk_base[j] + blockIdx.x;
+    const int epoch = __hip_atomic_load(x.local + kEpochBase + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    int64_t* my_step = step + 2 + step_slot_base + chunk;          // this workgroup's own copy of the optimizer's step number
+    int64_t steps_done = 0;
     if (threadIdx.x == 0) {
-        const double t = double(__hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * seg.nseg_total + seg.first + j + 1);
+        steps_done = __hip_atomic_load(my_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double t = double(steps_done * seg.nseg_total + seg.first + j + 1);
         inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
         inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
     }
     const bool vec = base_aligned && (begin & 3) == 0;
-    const int chunk = seg.chunk_base[j] + blockIdx.x;
+    // the LAST piece's parameter and moments are on their way while the exchange waits for the other ranks
+    const int64_t tail = first + int64_t(seg.pieces - 1) * kPiece + threadIdx.x * 4;
+    const int tail_valid = end - tail >= 4 ? 4 : (end > tail ? int(end - tail) : 0);
+    float P0[4], M0[4], V0[4];
+    if (tail_valid > 0) {
+        local_load(p + tail, tail_valid, vec, P0);
+        local_load(m + tail, tail_valid, vec, M0);
+        local_load(v + tail, tail_valid, vec, V0);
+    }
     float last[4] = {0.f, 0.f, 0.f, 0.f};
     exchange_chunk<false>(x, epoch, chunk, g, first, end, seg.pieces, vec, last);       // barriers inside: inv_bias is visible after it
     c.inv_bias1 = inv_bias[0];
     c.inv_bias2 = inv_bias[1];
-    for (int q = 0; q < seg.pieces; ++q) {
+    for (int q = 0; q + 1 < seg.pieces; ++q) {
         const int64_t elem = first + int64_t(q) * kPiece + threadIdx.x * 4;
         const int nvalid = end - elem >= 4 ? 4 : (end > elem ? int(end - elem) : 0);
         if (nvalid > 0) {
             float G[4], P[4], M[4], V[4];
-            if (q == seg.pieces - 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) G[e] = last[e];
-            } else {
-                local_load(g + elem, nvalid, vec, G);              // this thread's own stores of the reduced values
-            }
+            local_load(g + elem, nvalid, vec, G);                  // this thread's own stores of the reduced values
             local_load(p + elem, nvalid, vec, P);
             local_load(m + elem, nvalid, vec, M);
             local_load(v + elem, nvalid, vec, V);
@@ -285,7 +278,18 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
             local_store(v + elem, nvalid, vec, V);
         }
     }
-    arrive(x, chunk, seg.total_chunks, epoch, advance ? step : nullptr);
+    if (tail_valid > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adam_elem(P0[e], last[e], M0[e], V0[e], c);
+        local_store(p + tail, tail_valid, vec, P0);
+        local_store(m + tail, tail_valid, vec, M0);
+        local_store(v + tail, tail_valid, vec, V0);
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(x.local + kEpochBase + chunk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my_step, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (step_slot_base + chunk == 0) __hip_atomic_store(step, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the copy readers see
+    }
 }
 
 // ---- host state ---------------------------------------------------------------------------------------------------------
@@ -338,7 +342,7 @@ void p2p_describe_timeout(char* out, size_t len) {
         snprintf(out, len, "no record");
         return;
     }
-    snprintf(out, len, "rank %d of %d, at launch epoch %d: chunk %d waited for %s rank %d to reach epoch %d and saw %d", S.rank, S.nranks, rec[0],
+    snprintf(out, len, "rank %d of %d: chunk %d waited for %s rank %d to reach exchange %d of that chunk and saw %d", S.rank, S.nranks,
              rec[2], rec[5] == 1 ? "the push of" : "the sum from", rec[6], rec[3], rec[4]);
 }
 
@@ -375,8 +379,9 @@ extern "C" int lg_p2p_export(int rank, int nranks, int64_t capacity_floats, char
     }
     S.window = static_cast<char*>(w);
     LG_HIP(hipMemset(S.window, 0, S.bytes));
-    LG_HIP(hipMalloc(reinterpret_cast<void**>(&S.local), 4096));
-    LG_HIP(hipMemset(S.local, 0, 4096));
+    const size_t local_bytes = size_t(kEpochBase + S.max_chunks) * sizeof(int);
+    LG_HIP(hipMalloc(reinterpret_cast<void**>(&S.local), local_bytes));
+    LG_HIP(hipMemset(S.local, 0, local_bytes));
     LG_HIP(hipDeviceSynchronize());                               // the zeros are in place before any peer learns the handle
     hipIpcMemHandle_t h;
     LG_HIP(hipIpcGetMemHandle(&h, S.window));
@@ -442,8 +447,8 @@ extern "C" int lg_p2p_allreduce_f32(float* buf, int64_t n, int op) {
 }
 
 extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v, int nseg, const int64_t* offsets,
-                                         double lr, double b1, double b2, double eps, int64_t* step, double gscale,
-                                         int belief, int advance) {
+                                         double lr, double b1, double b2, double eps, int64_t* step, int64_t step_slots, double gscale,
+                                         int belief) {
     LG_REQUIRE_INIT();
     P2PState& S = st();
     LG_ARG(S.connected, "lg_p2p_adam_multi_dev_f32: lg_p2p_export / lg_p2p_connect first");
@@ -455,7 +460,8 @@ extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v,
     const P2PCtx x = make_ctx();
     const AdamScalars c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
     const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
-    for (int first = 0; first < nseg; first += kP2PMaxSegments) {  // groups of segments: one launch (and one epoch) each
+    int slot_base = 0;
+    for (int first = 0; first < nseg; first += kP2PMaxSegments) {  // groups of segments: one launch each
         const int count = nseg - first < kP2PMaxSegments ? nseg - first : kP2PMaxSegments;
         P2PSegments seg;
         seg.nseg = count;
@@ -485,9 +491,11 @@ extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v,
         seg.total_chunks = total;
         LG_ARG(total <= S.max_chunks, "lg_p2p_adam_multi_dev_f32: %d chunks exceed the window's %d flags", total, S.max_chunks);
         const unsigned grid_x = unsigned((longest + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece));
-        const int adv = (advance && first + count >= nseg) ? 1 : 0;             // the last group alone advances the step number
-        hipLaunchKernelGGL(adam_multi_p2p, dim3(grid_x, count), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2, adv, base_aligned, x);
+        LG_ARG(slot_base + total <= step_slots, "lg_p2p_adam_multi_dev_f32: %d chunks need as many step slots, the caller gave %lld (lghip_p2p.h)",
+               slot_base + total, (long long)step_slots);
+        hipLaunchKernelGGL(adam_multi_p2p, dim3(grid_x, count), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, slot_base, b1, b2, base_aligned, x);
         LG_CHECK_LAUNCH();
+        slot_base += total;
     }
     return LG_OK;
 }

@@ -101,7 +101,11 @@ class Adam(Optimizer):
         """data parallel with a communicator whose exchange rides in the optimizer launch (dist.PeerWindowCommunicator):
         step() first sums the flat gradient bucket over the ranks, in the same kernel"""
         assert self._flat is not None and hasattr(self._flat[0], "_fused_adam_multi_p2p"), "use_flat_buckets() first"
+        assert self.t == 0, "switch to the exchange inside the optimizer launch before the first step"
         self._peer_exchange = comm
+        offsets = self._flat[3]
+        chunks = sum(-(-(b - a) // 1024) for a, b in zip(offsets[:-1], offsets[1:]))
+        self._step_counter = self._flat[0]._new_step_counter(0, slots=chunks)     # one private copy of the step per exchange workgroup
 
     @Gradients.no_grad()
     def step(self) -> None:

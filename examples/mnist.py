@@ -98,26 +98,6 @@ def main():
         dt = time.perf_counter() - t0
         print("graph replay + per-step upload: final loss %.5f   %.1f steps/s (PCIe-inclusive, upload and compute in one stream)" % (final, args.steps / dt))
 
-        # the same loop with the NEXT batch prefetched on the copy stream from pinned host memory while the current
-        # step runs: a step costs max(DMA, compute) instead of their sum
-        pinned = []
-        for x, one_hot in batches:
-            px, pt = HipDevice.pinned_empty(x.shape), HipDevice.pinned_empty(one_hot.shape)
-            px[...], pt[...] = x, one_hot
-            pinned.append((px, pt))
-        HipDevice.synchronize()
-        t0 = time.perf_counter()
-        nxt = (HipTensor.prefetch(pinned[0][0]), HipTensor.prefetch(pinned[0][1]))
-        for i in range(args.steps):
-            x_static.commit_(nxt[0])
-            t_static.commit_(nxt[1])
-            px, pt = pinned[(i + 1) % len(pinned)]
-            nxt = (HipTensor.prefetch(px), HipTensor.prefetch(pt))        # overlaps with the replay below
-            graph.replay()
-            optim.on_graph_replay()
-        final = loss.item()
-        dt = time.perf_counter() - t0
-        print("graph replay + prefetch on the copy stream: final loss %.5f   %.1f steps/s (PCIe-inclusive, overlapped)" % (final, args.steps / dt))
         return
 
     optim = light.optim.AdaBelief(model.parameters(), lr=0.001, fused=not args.cpu)

@@ -66,19 +66,6 @@ int lg_device_info(lg_device_info_t* out);
 void* lg_stream(void);                          /* hipStream_t of the library (for liblghip_comm / profilers) */
 int lg_sync(void);                              /* block until the stream is idle */
 
-/* ---- side stream: work off the critical path ------------------------------------
- * New design (no reference analog: the reference's OpenCL backend has one in-order queue, opencl/device.py:68-115).
- * Launches (and the allocations they make) between lg_side_begin and lg_side_end go to a second, lower-priority HIP stream
- * that first waits for everything enqueued on the main stream so far; the main stream does NOT wait for them until
- * lg_side_join (also implied by lg_sync, lg_memcpy_d2h, lg_graph_launch, lg_graph_end, lg_pool_trim).  Meant for parameter
- * gradients: backward continues along the activation gradients while dW / db / LayerNorm and embedding gradients are
- * computed next to it.  Inside a captured graph the brackets become parallel branches.  The caller must not let the main
- * stream touch what a side launch writes before the join; blocks handed to lg_free while side work is pending are parked
- * until the join, so buffers a side launch READS may be released at any time.  Brackets do not nest. */
-int lg_side_begin(void);
-int lg_side_end(void);
-int lg_side_join(void);
-
 /* caching, stream-ordered allocator (replaces device.mem_pool.allocate, opencl/tensor.py:64).
  * lg_free returns the block to the pool immediately: safe because all users are on one stream. */
 int lg_malloc(void** ptr, size_t bytes);
@@ -93,15 +80,6 @@ int lg_memcpy_d2d(void* dst, const void* src, size_t bytes);   /* stream-ordered
 /* upload without waiting: src is staged into pinned memory (reusable on return), the DMA is stream-ordered.
  * Feeds a new batch into the static input tensor of a captured graph between two lg_graph_launch calls. */
 int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes);
-/* The same upload split in two so that it overlaps with compute: lg_prefetch_h2d starts the DMA of the NEXT batch on
- * a copy stream into a device staging slot (pinned sources - lg_host_malloc - are read in place, pageable ones are
- * staged first) and returns a slot id; lg_prefetch_commit makes the library's stream wait for that DMA and copies the
- * slot into `dst` device to device.  A step then costs max(DMA, compute), not their sum. */
-int lg_host_malloc(void** ptr, size_t bytes);              /* pinned host memory */
-int lg_host_free(void* ptr);
-int lg_prefetch_h2d(const void* src, size_t bytes, int* slot);
-int lg_prefetch_commit(int slot, void* dst, size_t bytes);
-
 /* HIP events on the library's stream (timing in bench.py) */
 int lg_event_create(void** ev);
 int lg_event_record(void* ev);
@@ -286,13 +264,15 @@ int lg_counter_add_i64(int64_t* counter, int64_t delta);
 
 /* All parameters of a model in one launch (groups of 64 parameters per launch beyond that): p, g, m, v are flat buckets holding `nseg` parameters
  * back to back, parameter j occupying [offsets[j], offsets[j+1]); its step number is
- * t = step[0] * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32.  `step` points at TWO int64:
- * step[0] the optimizer step, step[1] an arrival ticket that must be 0 between launches; with advance != 0
- * the last workgroup to finish increments step[0] - one contended atomic per workgroup (~11 ns each), so only
- * worth it for small grids; otherwise advance the counter with lg_counter_add_i64 (one tiny launch). */
+ * t = (steps done) * nseg + j + 1.  Same arithmetic as lg_adam_step_dev_f32.
+ *   step_slots == 0: step[0] holds the steps done and is only read (advance it with lg_counter_add_i64).
+ *   step_slots  > 0: the launch advances the step number itself, with no hand-off between workgroups: `step` points at
+ *     2 + step_slots int64 that all hold the steps done (zeros for a new optimizer); step[2 + s] is the private copy of
+ *     workgroup s of the launch grid, step[0] the copy readers see (step[1] is unused).  step_slots >= nseg *
+ *     ceil(longest parameter / 1024) always suffices. */
 int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
                           double lr, double b1, double b2, double eps,
-                          int64_t* step, double gscale, int belief, int advance);
+                          int64_t* step, int64_t step_slots, double gscale, int belief);
 
 /* ---- fused loss ----------------------------------------
  * loss.mse forward (loss.py:4-10) for dense fp32 tensors of n elements:
@@ -361,8 +341,7 @@ int lg_gemm_group_end(void);
  *   lg_head_fwd_f32   y = act(x) @ w^T + bias;  err = y + (-target);  row_loss[r] = sum_j err[r][j]^2
  *                     x: [rows, hidden] with row pitch ldx (hidden, ldx multiples of 4; x, w 16-byte aligned;
  *                     outs*hidden*4 <= 64 KiB), w: [outs, hidden] dense, bias: [outs] or NULL, target/y/err:
- *                     [rows, outs] dense, row_loss: [rows].  step_counter (or NULL): an int64 that is incremented
- *                     once - the optimizer's device step number rides along (see lg_adam_multi_dev_f32).
+ *                     [rows, outs] dense, row_loss: [rows].
  *   lg_mse_finalize_f32   loss[0] = (sum_r row_loss[r] * (1/n)) * 0.5 with n = rows*outs (loss.py:9-10): one small
  *                     launch, needed only when the loss is read before lg_head_bwd_f32 has run (which finishes it
  *                     with one extra workgroup, in the same summation order - same bits either way).
@@ -374,14 +353,11 @@ int lg_gemm_group_end(void);
  * They replace pyopencl launches of the reference's OpenCL backend: kernels.dot (opencl/ops.py:119-132),
  * kernels.atom (:285-288) and kernels.reduce (:344-368). */
 int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
-                    float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs, int64_t* step_counter);
+                    float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs);
 int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss);
 int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const float* g, const float* w,
                     float* dx, float* gpre, float* dw, int dw_accumulate, float* db, int db_accumulate,
                     int64_t rows, int64_t hidden, int64_t outs, const float* row_loss, float* loss);
-
-/* lg_mse_f32 with the same optional step-counter increment as lg_head_fwd_f32 */
-int lg_mse_bump_f32(const float* y, const float* y_hat, float* err, float* loss, int64_t n, int64_t* step_counter);
 
 /* ---- row-wise fused ops for the tiny-BERT path -------
  * Dense fp32 [rows, cols] operands; one wavefront owns a row.

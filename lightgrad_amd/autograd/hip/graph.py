@@ -26,16 +26,13 @@ class HipGraph(object):
 
     def __init__(self):
         self._exec = None
-        self._counter_events = ()       # what the recorded kernels do to waiting optimizer step counters (HipTensor._graph_replayed)
 
     @contextmanager
     def capture(self):
         assert self._exec is None, "HipGraph already holds a captured graph"
-        from .tensor import HipTensor
         L = _l.lib()
         _l.check(L.lg_graph_begin())
         HipGraph.capturing = True
-        HipTensor._capture_begins()
         handle = ctypes.c_void_p()
         try:
             yield self
@@ -44,22 +41,14 @@ class HipGraph(object):
             L.lg_graph_end(ctypes.byref(handle))     # leave capture mode, drop whatever was recorded
             if handle.value:
                 L.lg_graph_destroy(handle)
-            HipTensor._capture_ended(ok=False)
             raise
         HipGraph.capturing = False
-        rc = L.lg_graph_end(ctypes.byref(handle))
-        if rc != 0:
-            HipTensor._capture_ended(ok=False)
-            _l.check(rc)
+        _l.check(L.lg_graph_end(ctypes.byref(handle)))
         self._exec = handle
-        self._counter_events = tuple(HipTensor._capture_ended())      # also settles increments owed to the step before the capture
 
     def replay(self):
         assert self._exec is not None, "nothing captured"
         _l.check(_l._lib.lg_graph_launch(self._exec))
-        if self._counter_events:
-            from .tensor import HipTensor
-            HipTensor._graph_replayed(self._counter_events)
 
     def destroy(self):
         if self._exec is not None and _l._lib is not None:

@@ -41,19 +41,12 @@ PROTOTYPES = {
     "lg_device_info": (c_int, [POINTER(DeviceInfo)]),
     "lg_stream": (c_void_p, []),
     "lg_sync": (c_int, []),
-    "lg_side_begin": (c_int, []),
-    "lg_side_end": (c_int, []),
-    "lg_side_join": (c_int, []),
     "lg_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "lg_free": (c_int, [c_void_p]),
     "lg_pool_trim": (c_int, []),
     "lg_pool_stats": (c_int, [POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
     "lg_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t]),
-    "lg_host_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
-    "lg_host_free": (c_int, [c_void_p]),
-    "lg_prefetch_h2d": (c_int, [c_void_p, c_size_t, POINTER(c_int)]),
-    "lg_prefetch_commit": (c_int, [c_int, c_void_p, c_size_t]),
     "lg_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lg_event_create": (c_int, [POINTER(c_void_p)]),
@@ -84,7 +77,7 @@ PROTOTYPES = {
                                      c_double, c_void_p, c_int64, c_int64, c_double, c_int]),
     "lg_counter_add_i64": (c_int, [c_void_p, c_int64]),
     "lg_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
-                                      c_double, c_void_p, c_double, c_int, c_int]),
+                                      c_double, c_void_p, c_int64, c_double, c_int]),
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_gemm_addend_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
@@ -96,9 +89,8 @@ PROTOTYPES = {
     "lg_gemm_rowsum_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_int64, c_int, c_void_p, c_int]),
     "lg_mse_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64]),
-    "lg_mse_bump_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "lg_head_fwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_int64, c_int64, c_int64, c_void_p]),
+                                c_int64, c_int64, c_int64]),
     "lg_head_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                 c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "lg_mse_finalize_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),

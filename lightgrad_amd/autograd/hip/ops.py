@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 from ..func import Function
 import weakref
-from .tensor import HipTensor, HipBuffer, GradGroup, SideStream, contiguous_strides, flush_lazy_readers
+from .tensor import HipTensor, HipBuffer, GradGroup, contiguous_strides, flush_lazy_readers
 from . import lib as _l
 from .lib import i64
 
@@ -921,9 +921,6 @@ class getitem(Function):
                     ids_c, g_c = idx.contiguous(), out_grad.contiguous()        # (copies, if any, happen now, on the main chain)
                     with GradGroup.issue(reads=(ids_c, g_c), writes=(acc,)):    # queued: leaves with the LayerNorm gradients
                         _scatter_add_rows(shape, ids_c, g_c, into=acc)
-                elif SideStream.usable_for(table):
-                    with SideStream.bracket(reads=(idx, out_grad), writes=(acc,)):
-                        _scatter_add_rows(shape, idx, out_grad, into=acc)
                 else:
                     _scatter_add_rows(shape, idx, out_grad, into=acc)
                 table._notify_grad_written()
@@ -1186,12 +1183,6 @@ class linear(Function):
             with GradGroup.issue(reads=(g2, x2), writes=(acc_w, acc_b)):
                 linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
             return linear._input_product(x, weight, g2) + ((None,) if not has_bias else (None, None))
-        if in_place and SideStream.usable_for(weight, bias):
-            # deep tape: dW (+ db) go in place into the parameters' gradient buffers from the SIDE stream while the main
-            # stream carries on with dx, the only result the rest of the backward pass waits for
-            with SideStream.bracket(reads=(g2, x2), writes=(acc_w, acc_b)):
-                linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
-            return linear._input_product(x, weight, g2) + ((None,) if not has_bias else (None, None))
         # dW (+ db) and dx are independent products: when both are wanted they go out as ONE launch (lg_gemm_pair_*) - unless a
         # data-parallel exchange hangs on the weight gradient's kernel being enqueued the moment it is reported written
         paired = (weight.requires_grad and x.requires_grad and rows > 0 and weight._grad_written_hook is None
@@ -1364,9 +1355,8 @@ def head_mse_forward(y, y_hat):
     rows, hidden = x._shape
     outs = weight._shape[0]
     out, err, row_loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty((rows,), requires_grad=False)
-    counter = HipTensor._take_deferred_step_advance()
     _l.check(_l.lib().lg_head_fwd_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
-                                      out.ptr, err.ptr, row_loss.ptr, rows, hidden, outs, counter.ptr if counter is not None else None))
+                                      out.ptr, err.ptr, row_loss.ptr, rows, hidden, outs))
     y._data, y._offset, y._lazy_source = out._data, out._offset, None           # y is real now
     # the scalar loss stays lazy: the backward launch of this head finishes it (a cross-workgroup sum inside the forward
     # launch would cost 4 us); whoever reads it before that pays one small launch
@@ -1518,9 +1508,6 @@ class layer_norm(Function):
         if acc_w is not None and acc_b is not None and GradGroup.usable_for(weight, bias):
             with GradGroup.issue(reads=(g, xhat), writes=(acc_w, acc_b)):          # queued, like a Linear's dW
                 param_grads()
-        elif acc_w is not None and acc_b is not None and SideStream.usable_for(weight, bias):
-            with SideStream.bracket(reads=(g, xhat), writes=(acc_w, acc_b)):      # off the critical path on a second stream
-                param_grads()
         else:
             param_grads()
         if acc_w is not None:
@@ -1561,8 +1548,7 @@ def mse_forward(y, y_hat):
     assert y._shape == y_hat._shape, "mse: shapes %s and %s differ" % (y._shape, y_hat._shape)
     y, y_hat = y.contiguous(), y_hat.contiguous()
     err, loss = HipTensor.empty(y._shape), HipTensor.empty(())
-    counter = HipTensor._take_deferred_step_advance()       # an optimizer's step counter rides along (tensor.py)
-    _l.check(_l.lib().lg_mse_bump_f32(y.ptr, y_hat.ptr, err.ptr, loss.ptr, y.numel(), counter.ptr if counter is not None else None))
+    _l.check(_l.lib().lg_mse_f32(y.ptr, y_hat.ptr, err.ptr, loss.ptr, y.numel()))
     return loss, err
 
 

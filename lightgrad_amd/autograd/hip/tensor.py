@@ -133,98 +133,14 @@ class GradGroup(object):
             _l.check(_l.lib().lg_gemm_group_end())
 
 
-class SideStream(object):
-    """Parameter-gradient kernels on a second HIP stream (lg_side_* in include/lghip.h).
-
-    During a backward pass over a DEEP tape (a transformer: >= MIN_NODES tape nodes) the kernels that write parameter
-    gradients in place - dW / db of every Linear, LayerNorm's weight and bias gradients, embedding scatter-adds - do not sit
-    on the critical path: only the activation gradients feed the next node.  They are enqueued inside `with SideStream.bracket(...)`
-    and run next to the main chain (as parallel branches when the pass is captured into a hipGraph); the pass ends with a
-    join.  Shallow tapes (the MLP) keep everything on one stream - there the optimizer waits for every gradient at once and
-    one launch for dW and dx together is the better deal (lg_gemm_pair_*).
-
-    Hazards and how they are covered:
-      * a side kernel READS tensors made on the main stream: the bracket forks after everything enqueued so far, and lazy
-        operands are made real before the fork;
-      * it WRITES into gradient buffers: `written` remembers their storage until the join; an in-place writer on the main
-        stream (flush_lazy_readers is its hook) joins first;
-      * memory freed meanwhile is parked inside the library until the join."""
-    MIN_NODES = 48
-    # OFF unless asked for: measured on tiny-BERT (profiles/README.md r2) a hipGraph with these parallel branches replays in
-    # 3.8 ms instead of 0.86 ms - every edge between branches costs ~40 us in ROCm 7.2's graph executor - and the eager
-    # tape is host-bound either way.  GradGroup (above) gets the same work off the critical path inside ONE stream.
-    enabled = os.environ.get("LIGHTGRAD_SIDE_STREAM", "0") == "1"
-    depth = 0             # nested backward passes (WrapperFunction replays its inner tape with Gradients.backward)
-    active = False        # the running pass uses the side stream
-    in_bracket = False
-    written = set()       # id(HipBuffer) of storage with un-joined side writes
-
-    @staticmethod
-    def pass_begins(n_nodes):
-        S = SideStream
-        if S.depth == 0:
-            S.active = S.enabled and n_nodes >= S.MIN_NODES and not GradGroup.active
-        S.depth += 1
-        return S.pass_ends
-
-    @staticmethod
-    def pass_ends():
-        S = SideStream
-        S.depth -= 1
-        if S.depth == 0:
-            S.active = False
-            S.join()
-
-    @staticmethod
-    def join():
-        S = SideStream
-        if S.written:
-            S.written.clear()
-            _l.check(_l.lib().lg_side_join())
-
-    @staticmethod
-    def usable_for(*params) -> bool:
-        """may the gradients of these leaf parameters be written from the side stream?  Not when someone waits for the
-        moment they are enqueued (dist.DataParallel starts its exchange from that hook, on its own stream)"""
-        S = SideStream
-        if not S.active or S.in_bracket:
-            return False
-        for p in params:
-            if p is not None and p._grad_written_hook is not None:
-                return False
-        return True
-
-    class bracket(object):
-        __slots__ = ()
-
-        def __init__(self, reads, writes):
-            for t in reads:
-                if t is not None:
-                    t.data                      # lazy operands become real on the main stream, before the fork
-            for t in writes:
-                if t is not None:
-                    _make_lazy_readers_real(t)  # snapshots of the old contents, also before the fork
-                    SideStream.written.add(id(t._data))
-
-        def __enter__(self):
-            _l.check(_l.lib().lg_side_begin())
-            SideStream.in_bracket = True
-
-        def __exit__(self, *exc):
-            SideStream.in_bracket = False
-            _l.check(_l.lib().lg_side_end())
-
-
 def flush_lazy_readers(t) -> None:
     """call before any kernel WRITES into storage that already exists (in-place operators, fill, setitem, uploads,
     accumulating epilogues, optimizer updates, collectives): lazy tensors that were defined from the block's current
     contents (`relu` of a dense tensor, see HipTensor._lazy_source) are computed first, so that - like the reference,
     which evaluates relu at once (cpu/ops.py:226) - a later in-place change of the source never shows in them.
     Costs one attribute test when nobody is waiting (the normal case)."""
-    if SideStream.written and not SideStream.in_bracket and id(t._data) in SideStream.written:
-        SideStream.join()              # a main-stream writer into storage the side stream is still writing
     if GradGroup.touched and not GradGroup.issuing and id(t._data) in GradGroup.touched:
-        GradGroup.flush()              # ... or that a queued launch will read or write
+        GradGroup.flush()              # storage that a queued launch will read or write
     _make_lazy_readers_real(t)
 
 
@@ -236,14 +152,6 @@ def _make_lazy_readers_real(t) -> None:
             reader = ref()
             if reader is not None and reader._data is None:
                 reader._materialize()
-
-
-class PendingUpload(object):
-    """a host array on its way to a device staging slot (HipTensor.prefetch); consumed by HipTensor.commit_"""
-    __slots__ = ("slot", "shape", "dtype", "nbytes", "keepalive")
-
-    def __init__(self, slot, shape, dtype, nbytes, keepalive):
-        self.slot, self.shape, self.dtype, self.nbytes, self.keepalive = slot, tuple(shape), np.dtype(dtype), nbytes, keepalive
 
 
 class HipDevice(object):
@@ -271,19 +179,6 @@ class HipDevice(object):
         _l.check(_l.lib().lg_sync())
 
     @staticmethod
-    def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
-        """numpy array in pinned (page-locked) host memory: the DMA engine reads it in place, so `HipTensor.prefetch` /
-        `upload_` of such an array involve no host-side staging copy.  Freed when the array (and its views) die."""
-        import weakref
-        dtype = np.dtype(dtype)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        ptr = ctypes.c_void_p()
-        _l.check(_l.lib().lg_host_malloc(ctypes.byref(ptr), max(nbytes, 1)))
-        raw = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
-        weakref.finalize(raw, _l._lib.lg_host_free, ptr)
-        return np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
-
-    @staticmethod
     def pool_stats() -> dict:
         r, u, n = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         _l.check(_l.lib().lg_pool_stats(ctypes.byref(r), ctypes.byref(u), ctypes.byref(n)))
@@ -301,12 +196,7 @@ class HipTensor(AbstractTensor):
     @staticmethod
     def _backward_pass_begins(n_nodes):
         GradGroup.pass_begins(n_nodes)
-        side_ends = SideStream.pass_begins(n_nodes)
-
-        def ends():
-            GradGroup.pass_ends()
-            side_ends()
-        return ends
+        return GradGroup.pass_ends
 
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):
@@ -516,28 +406,6 @@ class HipTensor(AbstractTensor):
             _l.check(_l.lib().lg_memcpy_h2d_async(self.ptr, a.ctypes.data, a.nbytes))
         return self
 
-    @staticmethod
-    def prefetch(a: np.ndarray) -> "PendingUpload":
-        """start copying a host array to the device on the COPY stream and return at once; `tensor.commit_(pending)`
-        later makes the compute stream wait for that DMA and moves the data into `tensor`.  Prefetching batch i+1
-        before replaying the step on batch i overlaps the PCIe transfer with compute (examples/mnist.py --graph)."""
-        a = np.asarray(a)
-        if not a.flags["C_CONTIGUOUS"]:
-            a = a.copy(order="C")
-        assert a.nbytes > 0
-        slot = ctypes.c_int(-1)
-        _l.check(_l.lib().lg_prefetch_h2d(a.ctypes.data, a.nbytes, ctypes.byref(slot)))
-        return PendingUpload(slot.value, a.shape, a.dtype, a.nbytes, a)
-
-    def commit_(self, pending: "PendingUpload") -> "HipTensor":
-        assert self.is_contiguous() and pending.shape == self._shape and pending.dtype == self._dtype, \
-            "commit_: need a dense tensor of shape %s / dtype %s" % (pending.shape, pending.dtype)
-        assert pending.slot >= 0, "this prefetch has already been committed"
-        flush_lazy_readers(self)
-        _l.check(_l.lib().lg_prefetch_commit(pending.slot, self.ptr, pending.nbytes))
-        pending.slot, pending.keepalive = -1, None
-        return self
-
     def is_contiguous(self) -> bool:
         dense = self._dense                  # shape and strides of a tensor object never change after construction ...
         if dense is None:
@@ -615,18 +483,15 @@ class HipTensor(AbstractTensor):
         return cross_entropy_forward(self, labels)
 
     def _fused_adam_multi_dev(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
-        """self/grad/m/v are flat buckets holding len(offsets)-1 parameters: ONE launch updates them all"""
+        """self/grad/m/v are flat buckets holding len(offsets)-1 parameters: ONE launch updates them all and advances the step
+        counter (`_new_step_counter(step, slots=...)`: every workgroup keeps a copy of its own - csrc/optim.hip)"""
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         assert offsets[-1] == self.numel()
         flush_lazy_readers(self)
-        self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
-                                                lr, b1, b2, eps, step_counter.ptr, grad_scale, 1 if belief else 0, 0))
-        # advance = 0: the ticket form (the last working workgroup increments the counter) costs one contended atomic per
-        # working workgroup - measured 2 % slower per MLP step (~400 tickets) than a separate 1-thread launch.  Cheaper
-        # than both: the NEXT step's loss kernel carries the increment (see _advance_step_counter)
-        self._advance_step_counter(step_counter, defer=True)
+                                                lr, b1, b2, eps, step_counter.ptr, step_counter.numel() - 2, grad_scale,
+                                                1 if belief else 0))
 
     def _fused_adam_multi_p2p(self, grad, m, v, offsets, lr, b1, b2, eps, step_counter, grad_scale, belief):
         """`_fused_adam_multi_dev` of a data-parallel rank: the SAME launch first sums `grad` over the ranks through the peer
@@ -637,15 +502,14 @@ class HipTensor(AbstractTensor):
         assert offsets[-1] == self.numel()
         flush_lazy_readers(self)
         flush_lazy_readers(grad)
-        self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_p2p_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
                                                     lr, b1, b2, eps, step_counter.ptr, step_counter.numel() - 2, grad_scale,
                                                     1 if belief else 0))
 
     @staticmethod
     def _new_step_counter(step: int, slots: int = 0) -> "HipTensor":
-        """device-resident optimizer step number for graph-captured training steps: int64[2] = (step, arrival ticket), plus
-        `slots` private copies of the step for the workgroups of `_fused_adam_multi_p2p`"""
+        """device-resident optimizer step number for graph-captured training steps: int64[2 + slots] = (step, unused, then
+        `slots` private copies of the step for the workgroups of `_fused_adam_multi_dev` / `_fused_adam_multi_p2p`)"""
         return HipTensor.from_numpy(np.asarray([step, 0] + [step] * slots, dtype=np.int64), requires_grad=False)
 
     def _fused_adam_step_dev(self, grad, m, v, lr, b1, b2, eps, step_counter, t_mul, t_add, grad_scale, belief):
@@ -653,114 +517,13 @@ class HipTensor(AbstractTensor):
         for t in (self, grad, m, v):
             assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
         flush_lazy_readers(self)
-        self._flush_step_counter(step_counter)
         _l.check(_l.lib().lg_adam_step_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, self.numel(), lr, b1, b2, eps,
                                                step_counter.ptr, t_mul, t_add, grad_scale, 1 if belief else 0))
 
-    # Device step counters whose "+1" has not been enqueued yet.  An optimizer step ends by advancing its counter; that
-    # increment only has to land before the optimizer's NEXT kernel reads the counter, so instead of a 1-thread launch of
-    # its own (4 us of a 100 us training step) it waits here for a kernel that runs exactly once per training step anyway:
-    # the fused loss of the next forward pass (lg_head_fwd_f32 / lg_mse_bump_f32 take the counter as an argument).  If no
-    # such kernel came by, the optimizer flushes the increment itself before it reads the counter again.
-    #
-    # hipGraph capture (autograd/hip/graph.py calls _capture_begins / _capture_ended / _graph_replayed): a capture pass
-    # executes nothing, so the list is restored when it ends, and what the recorded kernels do to it - in order - is
-    # replayed with them:
-    #   * a loss kernel recorded in the capture carried a waiting increment -> an optimizer recorded after it defers again
-    #     (warm capture of one or several whole training steps: one increment per recorded step and no launch for it)
-    #   * nothing carried it -> the optimizer records its own 1-thread increment in the graph, as it would eagerly
-    #   * an increment of the step BEFORE the capture that no recorded kernel carried is executed once, when the capture
-    #     has ended (it belongs to that step, not to every replay)
-    _deferred_step_advances = []          # weak references: a counter dies with its optimizer
-    _capture_state = None                 # during a capture: {"snapshot", "own", "events", "owed"}
-
     @staticmethod
-    def _waiting_step_counters():
-        """the live counters with an increment waiting, oldest first (entries of dead optimizers are dropped)"""
-        alive = [(r, r()) for r in HipTensor._deferred_step_advances]
-        HipTensor._deferred_step_advances[:] = [r for r, c in alive if c is not None]
-        return [c for _, c in alive if c is not None]
-
-    @staticmethod
-    def _drop_waiting(step_counter):
-        """remove the oldest waiting entry of this counter; returns the entry (a weakref) or None"""
-        pending = HipTensor._deferred_step_advances
-        for i, ref in enumerate(pending):
-            if ref() is step_counter:
-                del pending[i]
-                return ref
-        return None
-
-    @staticmethod
-    def _advance_step_counter(step_counter, delta: int = 1, defer: bool = False) -> None:
-        if defer and delta == 1:
-            import weakref
-            cap = HipTensor._capture_state
-            if cap is None or any(kind == "take" and ref() is step_counter for kind, ref in cap["events"]):
-                entry = weakref.ref(step_counter)
-                HipTensor._deferred_step_advances.append(entry)
-                if cap is not None:
-                    cap["own"].append(entry)
-                    cap["events"].append(("defer", entry))
-                return
+    def _advance_step_counter(step_counter, delta: int = 1) -> None:
+        """one tiny launch: for optimizers whose update kernels only READ the counter (the per-parameter `_fused_adam_step_dev`)"""
         _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, delta))
-
-    @staticmethod
-    def _flush_step_counter(step_counter) -> None:
-        """the optimizer is about to read `step_counter`: enqueue an increment that is still waiting for a carrier"""
-        entry = HipTensor._drop_waiting(step_counter)
-        if entry is None:
-            return
-        cap = HipTensor._capture_state
-        if cap is not None and not any(entry is e for e in cap["own"]):
-            cap["owed"].append(step_counter)              # belongs to the step before the capture: executed once, afterwards
-            return
-        if cap is not None:
-            cap["events"].append(("take", entry))         # deferred inside this capture, settled inside it: recorded launch
-        _l.check(_l.lib().lg_counter_add_i64(step_counter.ptr, 1))
-
-    @staticmethod
-    def _take_deferred_step_advance():
-        """for a loss kernel of a TRAINING forward pass: the counter it should increment, or None"""
-        from ..grads import Gradients
-        # depth 1 = inside a first-class op's forward with gradients otherwise enabled; deeper = the user's no_grad()
-        if HipTensor._deferred_step_advances and Gradients._disable_depth == 1:
-            waiting = HipTensor._waiting_step_counters()
-            if waiting:
-                entry = HipTensor._deferred_step_advances.pop(0)
-                if HipTensor._capture_state is not None:
-                    HipTensor._capture_state["events"].append(("take", entry))
-                return waiting[0]
-        return None
-
-    @staticmethod
-    def _capture_begins() -> None:
-        HipTensor._capture_state = {"snapshot": list(HipTensor._deferred_step_advances), "own": [], "events": [], "owed": []}
-
-    @staticmethod
-    def _capture_ended(ok: bool = True):
-        """restore the waiting list (the capture pass executed nothing), settle what is owed to the step before the
-        capture, and hand the graph what its recorded kernels do to the list per replay: [("take" | "defer", counter ref)]"""
-        cap, HipTensor._capture_state = HipTensor._capture_state, None
-        HipTensor._deferred_step_advances[:] = cap["snapshot"]
-        if not ok:
-            return []
-        for counter in cap["owed"]:
-            HipTensor._drop_waiting(counter)
-            _l.check(_l.lib().lg_counter_add_i64(counter.ptr, 1))
-        return cap["events"]
-
-    @staticmethod
-    def _graph_replayed(events) -> None:
-        import weakref
-        for kind, ref in events:
-            c = ref()
-            if c is None:
-                continue
-            if kind == "take":
-                HipTensor._drop_waiting(c)
-            else:
-                HipTensor._deferred_step_advances.append(weakref.ref(c))
 
     def __repr__(self):
         return "HipTensor(shape=%s, strides=%s, dtype=%s)" % (self._shape, self._strides, self._dtype)

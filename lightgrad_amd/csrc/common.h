@@ -21,14 +21,6 @@ struct Runtime {
     // arrives last at a tile folds the partial products and resets the counter
     int*        gemm_tickets = nullptr;
     int         n_gemm_tickets = 0;
-    // Second stream for work off the critical path (lg_side_begin / _end / _join, include/lghip.h).  Inside a bracket `stream`
-    // and `gemm_tickets` ARE the side stream's: every launch site reads them from here, so kernels need no changes.
-    hipStream_t main_stream = nullptr, side_stream = nullptr;
-    hipEvent_t  side_fork_ev = nullptr, side_join_ev = nullptr;
-    int*        tickets_main = nullptr;
-    int*        tickets_side = nullptr;
-    bool        side_open = false;      // between lg_side_begin and lg_side_end
-    bool        side_dirty = false;     // the side stream has work the main stream has not waited for yet
     // device status flag: one int in pinned, device-mapped host memory.  Kernels that meet an index / label out of
     // range OR a bit into it (system scope); lg_sync / lg_memcpy_d2h read it from the host side after their stream
     // synchronisation and report LG_EINDEX once.
@@ -51,12 +43,10 @@ bool capturing();
 bool gemm_group_is_open();
 int gemm_group_flush_pending();
 int ln_group_flush_pending();
+bool ln_group_writes(const void* ptr);
 
 // p2p.hip: what the first wait of the peer-window exchange that gave up was waiting for
 void p2p_describe_timeout(char* out, size_t len);
-
-// main stream waits for the side stream, blocks freed meanwhile return to the pool (no-op when nothing is pending)
-int side_join();
 
 }  // namespace lg
 

@@ -365,7 +365,11 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
     bool clash = false;
     for (int i = 0; i < G.count; ++i)
         clash = clash || G.grp.p[i].C == g.C || (g.rowsum && G.grp.p[i].rowsum == g.rowsum);
-    if (clash || G.count == kGroupMax || G.tiles + tiles > rt().n_gemm_tickets / 2) {     // (the upper half: LayerNorm's queue)
+    if (ln_group_writes(g.C) || ln_group_writes(g.rowsum)) {
+        // an embedding scatter / LayerNorm gradient queued EARLIER writes the same buffer: everything queued leaves now, in call order
+        rc = gemm_group_flush_pending();
+        if (rc != LG_OK) return false;
+    } else if (clash || G.count == kGroupMax || G.tiles + tiles > rt().n_gemm_tickets / 2) {     // (the upper half: LayerNorm's queue)
         rc = group_flush();
         if (rc != LG_OK) return false;
     }

@@ -9,8 +9,7 @@
 //              - nn.py:96 + loss.py:4-8 of the reference.  The scalar loss (sum row_loss * (1/N)) * 0.5 (loss.py:9-10) is
 //              NOT folded here: a cross-workgroup hand-off inside the launch costs 4 us (measured: 9.0 us with it, 5.0
 //              without; an empty launch is 3.0) - it is finished by one extra workgroup of head_bwd, or by
-//              lg_mse_finalize_f32 when somebody reads the loss first.  Optionally advances a device step counter
-//              (the optimizer's, see optim.hip): a kernel that runs once per step carries that increment for free.
+//              lg_mse_finalize_f32 when somebody reads the loss first.
 //   head_bwd   dx = g @ W,  g_pre = dx * (pre >= 0),  dW = g^T @ act(x),  db = column sums of g
 //              one launch, three kinds of workgroups, no hand-off between them: "slab" workgroups own 8 columns of dW
 //              over ALL rows (g staged in LDS, sums over thread rows through LDS in a fixed order), "tile" workgroups
@@ -60,7 +59,6 @@ struct HeadFwd {
     float*       y;        // [rows, outs]
     float*       err;      // [rows, outs]
     float*       row_loss; // [rows]
-    int64_t*     bump;     // optional: bump[0] += 1 (once per launch)
     int64_t      rows, ldx;
     int          hidden, outs, relu;
 };
@@ -71,7 +69,6 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = a.outs * a.hidden;
     for (int i = tid * 4; i < wn; i += 1024) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(a.w + i);
-    if (a.bump && blockIdx.x == 0 && tid == 0) a.bump[0] += 1;             // nobody else in this launch looks at it
     __syncthreads();
     for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < a.rows; row += int64_t(gridDim.x) * 4) {
         float acc[OMAX];
@@ -289,8 +286,7 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
 using namespace lg;
 
 extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
-                               float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs,
-                               int64_t* step_counter) {
+                               float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs) {
     LG_REQUIRE_INIT();
     LG_ARG(rows > 0 && hidden > 0 && outs > 0 && outs <= 16, "lg_head_fwd_f32: need rows > 0, hidden > 0, 1 <= outs <= 16 (got %lld, %lld, %lld)",
            (long long)rows, (long long)hidden, (long long)outs);
@@ -301,7 +297,6 @@ extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const floa
     HeadFwd a{};
     a.x = x; a.w = w; a.bias = bias; a.target = target; a.y = y; a.err = err; a.row_loss = row_loss;
     a.rows = rows; a.ldx = ldx; a.hidden = int(hidden); a.outs = int(outs); a.relu = relu;
-    a.bump = step_counter;
     int64_t grid = (rows + 3) / 4;
     if (grid > 1024) grid = 1024;
     const size_t lds = size_t(outs * hidden) * sizeof(float);

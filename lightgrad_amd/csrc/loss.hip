@@ -35,21 +35,17 @@ __global__ void __launch_bounds__(256) mse_partial(const float* __restrict__ y, 
 }
 
 // one block: sums `count` partials in index order and applies (sum * inv_n) * 0.5
-__global__ void __launch_bounds__(256) mse_final(const float* __restrict__ partial, int count, float* __restrict__ loss, float inv_n,
-                                                 int64_t* bump) {
+__global__ void __launch_bounds__(256) mse_final(const float* __restrict__ partial, int count, float* __restrict__ loss, float inv_n) {
     __shared__ float lds[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
     const float s = block_sum<4>(acc, lds);
-    if (threadIdx.x == 0) {
-        loss[0] = (s * inv_n) * 0.5f;
-        if (bump) bump[0] += 1;
-    }
+    if (threadIdx.x == 0) loss[0] = (s * inv_n) * 0.5f;
 }
 
 // small inputs: a single block does both steps
 __global__ void __launch_bounds__(1024) mse_single(const float* __restrict__ y, const float* __restrict__ t, float* __restrict__ err,
-                                                   float* __restrict__ loss, int64_t n, float inv_n, int vec, int64_t* bump) {
+                                                   float* __restrict__ loss, int64_t n, float inv_n, int vec) {
     __shared__ float lds[16];
     float acc = 0.f;
     int64_t done = 0;
@@ -70,23 +66,14 @@ __global__ void __launch_bounds__(1024) mse_single(const float* __restrict__ y, 
         acc += e * e;
     }
     const float s = block_sum<16>(acc, lds);
-    if (threadIdx.x == 0) {
-        loss[0] = (s * inv_n) * 0.5f;
-        if (bump) bump[0] += 1;          // an optimizer's device step counter rides along (optim.hip): one launch less per step
-    }
+    if (threadIdx.x == 0) loss[0] = (s * inv_n) * 0.5f;
 }
 
 }  // namespace lg
 
 using namespace lg;
 
-extern "C" int lg_mse_bump_f32(const float* y, const float* t, float* err, float* loss, int64_t n, int64_t* bump);
-
 extern "C" int lg_mse_f32(const float* y, const float* t, float* err, float* loss, int64_t n) {
-    return lg_mse_bump_f32(y, t, err, loss, n, nullptr);
-}
-
-extern "C" int lg_mse_bump_f32(const float* y, const float* t, float* err, float* loss, int64_t n, int64_t* bump) {
     LG_REQUIRE_INIT();
     LG_ARG(n > 0, "lg_mse_f32: empty input");
     LG_ARG(y && t && err && loss, "lg_mse_f32: NULL pointer");
@@ -94,14 +81,14 @@ extern "C" int lg_mse_bump_f32(const float* y, const float* t, float* err, float
     const float inv_n = float(1.0 / double(n));      // python's `s.numel() / t.numel()` rounded once to fp32
     if (n <= 32768) {
         hipLaunchKernelGGL(mse_single, dim3(1), dim3(1024), 0, s, y, t, err, loss, n, inv_n,
-                           int(aligned16(y) && aligned16(t) && aligned16(err)), bump);
+                           int(aligned16(y) && aligned16(t) && aligned16(err)));
     } else {
         const unsigned blocks = unsigned(((n + 1023) / 1024) < 4096 ? ((n + 1023) / 1024) : 4096);   // partial sums to combine
         float* partial = nullptr;
         int rc = lg_malloc(reinterpret_cast<void**>(&partial), blocks * sizeof(float));
         if (rc != LG_OK) return rc;
         hipLaunchKernelGGL(mse_partial, dim3(blocks), dim3(256), 0, s, y, t, err, partial, n);
-        hipLaunchKernelGGL(mse_final, dim3(1), dim3(256), 0, s, partial, int(blocks), loss, inv_n, bump);
+        hipLaunchKernelGGL(mse_final, dim3(1), dim3(256), 0, s, partial, int(blocks), loss, inv_n);
         rc = lg_free(partial);
         if (rc != LG_OK) return rc;
     }

@@ -115,7 +115,14 @@ extern "C" int lg_counter_add_i64(int64_t* counter, int64_t delta) {
 
 // ---- multi-tensor form: all parameters of a model in ONE launch --------------------------------
 // p, g, m, v are flat buckets holding nseg parameters back to back (offsets[j] .. offsets[j+1]);
-// blockIdx.y selects the parameter, whose step number is t = *step * nseg + j + 1 (optim.py:36/:48).
+// blockIdx.y selects the parameter, whose step number is t = steps_done * nseg + j + 1 (optim.py:36/:48).
+//
+// Who advances the step number.  With step_slots > 0 the launch does, and without any hand-off between workgroups:
+// step[2 + s] is the private copy of the workgroup with slot s = slot_base + blockIdx.y * gridDim.x + blockIdx.x - read
+// when it starts, incremented when it ends, by the same workgroup index in every launch (same bucket, same grid) - and
+// one workgroup mirrors it into step[0] for readers.  A shared word would need a "last workgroup" (an arrival ticket
+// per workgroup: measured 2 % of the MLP step) or a carrier kernel elsewhere in the step (round 2: the loss kernel of
+// the NEXT step, with bookkeeping across hipGraph captures that went wrong for separately captured graphs).
 namespace lg {
 
 constexpr int kMaxSegments = 64;
@@ -123,99 +130,74 @@ struct AdamSegments {
     int     nseg;          // parameters in THIS launch (<= kMaxSegments)
     int     nseg_total;    // parameters of the optimizer: the reference's `t` advances once per parameter (optim.py:36/:48)
     int     first;         // index of this launch's first parameter
+    int     slot_base;     // step slot of workgroup (0, 0) of this launch
+    int     mirror_slot;   // the workgroup with this slot also writes step[0] (-1: none in this launch)
     int64_t offsets[kMaxSegments + 1];
 };
 
 __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, AdamSegments seg, AdamScalars c,
-                                                      int64_t* __restrict__ step, double b1, double b2, int advance, int base_aligned) {
+                                                      int64_t* __restrict__ step, double b1, double b2, int own_slots, int base_aligned) {
     __shared__ float inv_bias[2];
     const int j = blockIdx.y;
     const int64_t begin = seg.offsets[j], n = seg.offsets[j + 1] - begin;
     // four elements per thread where the segment allows 16-byte accesses (vec == 1), else one
     const int vec = (base_aligned && (begin & 3) == 0) ? 1 : 0;
     const int64_t first = (int64_t(blockIdx.x) * blockDim.x) * (vec ? 4 : 1);
-    if (first < n) {                                   // workgroup-uniform
-        if (threadIdx.x == 0) {
-            // the two double-precision powers once per workgroup, not once per thread (they were most of the kernel)
-            const double t = double(step[0] * seg.nseg_total + seg.first + j + 1);
-            inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
-            inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
-        }
-        __syncthreads();
-        c.inv_bias1 = inv_bias[0];
-        c.inv_bias2 = inv_bias[1];
-        float* P = p + begin;
-        const float* G = g + begin;
-        float* M = m + begin;
-        float* V = v + begin;
-        if (vec) {
-            const int64_t nvec = n / 4, stride = int64_t(gridDim.x) * blockDim.x;
-            for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-                float4 pp = reinterpret_cast<float4*>(P)[i], gg = reinterpret_cast<const float4*>(G)[i];
-                float4 mm = reinterpret_cast<float4*>(M)[i], vv = reinterpret_cast<float4*>(V)[i];
-                adam_elem(pp.x, gg.x, mm.x, vv.x, c);
-                adam_elem(pp.y, gg.y, mm.y, vv.y, c);
-                adam_elem(pp.z, gg.z, mm.z, vv.z, c);
-                adam_elem(pp.w, gg.w, mm.w, vv.w, c);
-                reinterpret_cast<float4*>(P)[i] = pp;
-                reinterpret_cast<float4*>(M)[i] = mm;
-                reinterpret_cast<float4*>(V)[i] = vv;
-            }
-            if (blockIdx.x == 0)
-                for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) adam_elem(P[i], G[i], M[i], V[i], c);
-        } else {
-            const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-            for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
-        }
+    if (first >= n) return;                            // workgroup-uniform
+    const int slot = seg.slot_base + j * int(gridDim.x) + int(blockIdx.x);
+    int64_t steps_done = 0;
+    if (threadIdx.x == 0) {
+        // the two double-precision powers once per workgroup, not once per thread (they were most of the kernel)
+        steps_done = __hip_atomic_load(own_slots ? step + 2 + slot : step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double t = double(steps_done * seg.nseg_total + seg.first + j + 1);
+        inv_bias[0] = float(1.0 / (1.0 - pow(b1, t)));
+        inv_bias[1] = float(1.0 / (1.0 - pow(b2, t)));
     }
-    if (advance > 0 && first < n) {
-        // the LAST working workgroup to finish advances the step number (step[1] is an arrival ticket, zero between
-        // launches; `advance` = number of workgroups that have work): every workgroup has read step[0] before it draws
-        // its ticket, so the write cannot race with a read
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long ticket = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ULL);
-            if (ticket == (unsigned long long)advance - 1) {
-                step[1] = 0;
-                step[0] = step[0] + 1;
-            }
+    __syncthreads();
+    c.inv_bias1 = inv_bias[0];
+    c.inv_bias2 = inv_bias[1];
+    float* P = p + begin;
+    const float* G = g + begin;
+    float* M = m + begin;
+    float* V = v + begin;
+    if (vec) {
+        const int64_t nvec = n / 4, stride = int64_t(gridDim.x) * blockDim.x;
+        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            float4 pp = reinterpret_cast<float4*>(P)[i], gg = reinterpret_cast<const float4*>(G)[i];
+            float4 mm = reinterpret_cast<float4*>(M)[i], vv = reinterpret_cast<float4*>(V)[i];
+            adam_elem(pp.x, gg.x, mm.x, vv.x, c);
+            adam_elem(pp.y, gg.y, mm.y, vv.y, c);
+            adam_elem(pp.z, gg.z, mm.z, vv.z, c);
+            adam_elem(pp.w, gg.w, mm.w, vv.w, c);
+            reinterpret_cast<float4*>(P)[i] = pp;
+            reinterpret_cast<float4*>(M)[i] = mm;
+            reinterpret_cast<float4*>(V)[i] = vv;
         }
+        if (blockIdx.x == 0)
+            for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) adam_elem(P[i], G[i], M[i], V[i], c);
+    } else {
+        const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
+    }
+    if (own_slots && threadIdx.x == 0) {
+        __hip_atomic_store(step + 2 + slot, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot == seg.mirror_slot) __hip_atomic_store(step, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 }  // namespace lg
 
+// launches one group of <= kMaxSegments parameters; returns the number of step slots the group's grid spans in *slots_used
 static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets, int first, int nseg_total,
-                               double lr, double b1, double b2, double eps, int64_t* step, double gscale, int belief, int advance);
-
-extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
-                                     double lr, double b1, double b2, double eps, int64_t* step, double gscale,
-                                     int belief, int advance) {
-    LG_REQUIRE_INIT();
-    LG_ARG(nseg >= 1, "lg_adam_multi_dev_f32: %d segments", nseg);
-    LG_ARG(p && g && m && v && step && offsets, "lg_adam_multi_dev_f32: NULL pointer");
-    if (nseg > kMaxSegments) {
-        // more parameters than one launch's argument block holds (tiny-BERT has 40+, larger models hundreds): groups of
-        // kMaxSegments, one launch each.  Every group reads the same step[0]; with the ticket form the LAST group alone
-        // advances it (stream order: the earlier groups have finished reading by then).
-        for (int first = 0; first < nseg; first += kMaxSegments) {
-            const int count = nseg - first < kMaxSegments ? nseg - first : kMaxSegments;
-            const int rc = lg_adam_multi_group(p, g, m, v, count, offsets + first, first, nseg, lr, b1, b2, eps, step, gscale, belief,
-                                               (advance && first + count == nseg) ? 1 : 0);
-            if (rc != LG_OK) return rc;
-        }
-        return LG_OK;
-    }
-    return lg_adam_multi_group(p, g, m, v, nseg, offsets, 0, nseg, lr, b1, b2, eps, step, gscale, belief, advance);
-}
-
-static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets, int first, int nseg_total,
-                               double lr, double b1, double b2, double eps, int64_t* step, double gscale, int belief, int advance) {
+                               double lr, double b1, double b2, double eps, int64_t* step, int64_t step_slots, int slot_base, bool* mirrored,
+                               double gscale, int belief, int* slots_used) {
     AdamSegments seg;
     seg.nseg = nseg;
     seg.nseg_total = nseg_total;
     seg.first = first;
+    seg.slot_base = slot_base;
+    seg.mirror_slot = -1;
     int64_t longest = 0;
     for (int j = 0; j <= nseg; ++j) {
         seg.offsets[j] = offsets[j];
@@ -224,26 +206,44 @@ static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int
             if (offsets[j] - offsets[j - 1] > longest) longest = offsets[j] - offsets[j - 1];
         }
     }
+    *slots_used = 0;
     if (longest == 0) return LG_OK;
-    AdamScalars c;
-    c.neg_lr = float(-lr); c.b1 = float(b1); c.one_minus_b1 = float(1.0 - b1); c.b2 = float(b2); c.one_minus_b2 = float(1.0 - b2);
-    c.eps = float(eps); c.inv_bias1 = 0.f; c.inv_bias2 = 0.f; c.gscale = float(gscale); c.belief = belief;
-    c.scale_grad = gscale != 1.0;
+    const AdamScalars c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
     // sized for four elements per thread (segments that do not start on a 16-byte boundary loop: grid-stride)
     const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
     const int64_t grid_x = stream_grid((longest + 3) / 4);
-    if (advance) {                    // number of workgroups with work: they take the arrival tickets
-        int64_t active = 0;
-        for (int j = 0; j < nseg; ++j) {
-            const int64_t n = offsets[j + 1] - offsets[j];
-            const int64_t per_wg = 256 * ((base_aligned && (offsets[j] & 3) == 0) ? 4 : 1);
-            const int64_t wgs = (n + per_wg - 1) / per_wg;
-            active += wgs < grid_x ? wgs : grid_x;
-        }
-        advance = int(active);
+    *slots_used = int(grid_x) * nseg;
+    if (step_slots > 0) {
+        LG_ARG(slot_base + *slots_used <= step_slots, "lg_adam_multi_dev_f32: the grid spans %d step slots, the caller gave %lld (lghip.h)",
+               slot_base + *slots_used, (long long)step_slots);
+        if (!*mirrored)                                   // workgroup (0, j) of the first non-empty parameter keeps step[0] current
+            for (int j = 0; j < nseg; ++j)
+                if (offsets[j + 1] > offsets[j]) { seg.mirror_slot = slot_base + j * int(grid_x); *mirrored = true; break; }
     }
     hipLaunchKernelGGL(adam_multi_dev, dim3(unsigned(grid_x), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
-                       advance, base_aligned);
+                       step_slots > 0 ? 1 : 0, base_aligned);
     LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg, const int64_t* offsets,
+                                     double lr, double b1, double b2, double eps, int64_t* step, int64_t step_slots, double gscale,
+                                     int belief) {
+    LG_REQUIRE_INIT();
+    LG_ARG(nseg >= 1, "lg_adam_multi_dev_f32: %d segments", nseg);
+    LG_ARG(p && g && m && v && step && offsets, "lg_adam_multi_dev_f32: NULL pointer");
+    LG_ARG(step_slots >= 0, "lg_adam_multi_dev_f32: negative step_slots");
+    // more parameters than one launch's argument block holds (tiny-BERT has 40+, larger models hundreds): groups of
+    // kMaxSegments, one launch each, every group with step slots of its own
+    int slot_base = 0;
+    bool mirrored = false;
+    for (int first = 0; first < nseg; first += kMaxSegments) {
+        const int count = nseg - first < kMaxSegments ? nseg - first : kMaxSegments;
+        int used = 0;
+        const int rc = lg_adam_multi_group(p, g, m, v, count, offsets + first, first, nseg, lr, b1, b2, eps, step, step_slots, slot_base, &mirrored,
+                                           gscale, belief, &used);
+        if (rc != LG_OK) return rc;
+        slot_base += used;
+    }
     return LG_OK;
 }

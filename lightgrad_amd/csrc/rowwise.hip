@@ -604,6 +604,18 @@ struct LnGroupState {
 };
 static LnGroupState& ln_group() { static LnGroupState s; return s; }
 
+// does a queued LayerNorm parameter gradient or embedding scatter write (into) `ptr`?  A GEMM product that arrives later for the same
+// buffer must not be queued in front of it (the GEMM queue leaves first): gemm.hip flushes everything, in order, before it queues
+bool ln_group_writes(const void* ptr) {
+    LnGroupState& S = ln_group();
+    if (ptr == nullptr) return false;
+    for (int i = 0; i < S.count; ++i)
+        if (S.grp.ln.e[i].dw == ptr || S.grp.ln.e[i].db == ptr) return true;
+    for (int i = 0; i < S.n_scatter; ++i)
+        if (S.grp.sc[i].table == ptr) return true;
+    return false;
+}
+
 int ln_group_flush_pending() {
     LnGroupState& S = ln_group();
     if (S.count == 0 && S.n_scatter == 0) return LG_OK;
@@ -720,7 +732,9 @@ extern "C" int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, i
         bool clash = false;
         for (int i = 0; i < S.n_scatter; ++i) clash = clash || S.grp.sc[i].table == grad_table;        // tied tables: in call order
         if (clash || S.n_scatter == kScatterGroupMax) {
-            const int rc = ln_group_flush_pending();
+            // an early flush sends the queued GEMM products FIRST: one of them may still have to OVERWRITE the very buffer a queued
+            // scatter adds into (a tied embedding / decoder weight after zero_grad: dW comes with beta = 0) - call order is kept
+            const int rc = gemm_group_flush_pending();
             if (rc != LG_OK) return rc;
         }
         ScatterJob& j = S.grp.sc[S.n_scatter++];
@@ -844,7 +858,7 @@ extern "C" int lg_layernorm_param_grads_f32(const float* g, const float* xhat, f
         bool clash = false;
         for (int i = 0; i < S.count; ++i) clash = clash || S.grp.ln.e[i].dw == dw || S.grp.ln.e[i].db == db;
         if (clash || S.count == kLnGroupMax || S.tickets + blocks_x > rt().n_gemm_tickets / 2 - 1) {      // (the very last slot: the loss kernel's)
-            const int rc = ln_group_flush_pending();
+            const int rc = gemm_group_flush_pending();      // queued GEMM products first, then this group: call order (see lg_scatter_add_rows_f32)
             if (rc != LG_OK) return rc;
         }
         a.tickets = rt().gemm_tickets + rt().n_gemm_tickets / 2 + S.tickets;

@@ -50,9 +50,6 @@ struct Pool {
     std::multimap<size_t, void*>     free_blocks;     // cached, general
     std::unordered_map<void*, Block> all;             // every hipMalloc'ed block (live or cached)
     uint64_t reserved = 0, in_use = 0, hip_mallocs = 0;
-    // blocks freed while the side stream had un-joined work: a kernel on the OTHER stream may still use them, so they go
-    // back to the pool only at the join (lg_side_join)
-    std::vector<std::pair<void*, Block>> quarantine;
     // graph capture state
     GraphRec* capture = nullptr;
     int next_graph_id = 1;
@@ -158,22 +155,12 @@ int lg_init(int device) {
     } else {
         LG_HIP(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
     }
-    R.main_stream = R.stream;
-    {
-        int least = 0, greatest = 0;                      // numerically greatest = lowest priority: the main chain wins contended CUs
-        LG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        LG_HIP(hipStreamCreateWithPriority(&R.side_stream, hipStreamNonBlocking, least));
-        LG_HIP(hipEventCreateWithFlags(&R.side_fork_ev, hipEventDisableTiming));
-        LG_HIP(hipEventCreateWithFlags(&R.side_join_ev, hipEventDisableTiming));
-    }
     hipDeviceProp_t prop;
     LG_HIP(hipGetDeviceProperties(&prop, device));
     R.compute_units = prop.multiProcessorCount;
     R.n_gemm_tickets = 1 << 16;
-    LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.tickets_main), size_t(2) * R.n_gemm_tickets * sizeof(int)));
-    LG_HIP(hipMemset(R.tickets_main, 0, size_t(2) * R.n_gemm_tickets * sizeof(int)));    // synchronous: ordered before any launch on either stream
-    R.tickets_side = R.tickets_main + R.n_gemm_tickets;       // concurrent launches on the two streams never share a ticket
-    R.gemm_tickets = R.tickets_main;
+    LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.gemm_tickets), size_t(R.n_gemm_tickets) * sizeof(int)));
+    LG_HIP(hipMemset(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int)));    // synchronous: ordered before any launch
     LG_HIP(hipHostMalloc(reinterpret_cast<void**>(&R.status_host), 64, hipHostMallocMapped));
     R.status_host[0] = 0;
     LG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&R.status_dev), R.status_host, 0));
@@ -209,79 +196,16 @@ int lg_device_info(lg_device_info_t* out) {
     return LG_OK;
 }
 
-void* lg_stream(void) { return rt().ready ? static_cast<void*>(rt().main_stream) : nullptr; }
+void* lg_stream(void) { return rt().ready ? static_cast<void*>(rt().stream) : nullptr; }
 
-// ---- side stream -----------------------------------------------------------------
-// Kernels whose results nobody on the main stream needs soon (parameter gradients, while backward walks on along the
-// activation gradients) are enqueued between lg_side_begin and lg_side_end: they run on a second, lower-priority stream that
-// first waits for everything enqueued on the main stream so far.  lg_side_join makes the main stream wait for them.  While
-// captured into a hipGraph the brackets become parallel branches of the graph.  Memory: a block freed while side work is
-// pending may still be in use on the other stream, so frees are parked until the join.
-
-int lg_side_begin(void) {
-    LG_REQUIRE_INIT();
-    Runtime& R = rt();
-    LG_ARG(!R.side_open, "lg_side_begin: a side bracket is already open");
-    LG_HIP(hipEventRecord(R.side_fork_ev, R.main_stream));
-    LG_HIP(hipStreamWaitEvent(R.side_stream, R.side_fork_ev, 0));
-    R.stream = R.side_stream;
-    R.gemm_tickets = R.tickets_side;
-    R.side_open = true;
-    R.side_dirty = true;
-    return LG_OK;
-}
-
-int lg_side_end(void) {
-    LG_REQUIRE_INIT();
-    Runtime& R = rt();
-    LG_ARG(R.side_open, "lg_side_end: no side bracket is open");
-    R.stream = R.main_stream;
-    R.gemm_tickets = R.tickets_main;
-    R.side_open = false;
-    return LG_OK;
-}
-
-}  // extern "C"
-
-namespace lg {
-int side_join() {
-    Runtime& R = rt();
-    { const int rc = gemm_group_flush_pending(); if (rc != LG_OK) return rc; }     // queued products count as pending work too
-    if (!R.side_dirty) return LG_OK;
-    if (R.side_open) { set_error("lg_side_join: a side bracket is still open"); return LG_EINVAL; }
-    LG_HIP(hipEventRecord(R.side_join_ev, R.side_stream));
-    LG_HIP(hipStreamWaitEvent(R.main_stream, R.side_join_ev, 0));
-    R.side_dirty = false;
-    Pool& P = pool();
-    std::vector<std::pair<void*, Block>> parked;
-    {
-        std::lock_guard<std::mutex> lock(P.mu);
-        parked.swap(P.quarantine);
-        for (auto& pb : parked) {                 // what lg_free does for a block nobody else can be using
-            Block b = pb.second;
-            if (b.graph != 0) {
-                auto g = P.graphs.find(b.graph);
-                if (g != P.graphs.end()) { g->second->free_blocks.emplace(b.bytes, pb.first); continue; }
-                P.all[pb.first].graph = 0;
-            }
-            P.free_blocks.emplace(b.bytes, pb.first);
-        }
-    }
-    return LG_OK;
-}
-}  // namespace lg
-
-extern "C" {
-
-int lg_side_join(void) {
-    LG_REQUIRE_INIT();
-    return side_join();
-}
+// queued work (lg_gemm_group_*: weight-gradient products, LayerNorm parameter gradients, embedding scatter-adds) is launched
+// before anything that exposes results to the host, to another graph or to the allocator's trim
+static int flush_queued() { return lg::gemm_group_flush_pending(); }
 
 int lg_sync(void) {
     LG_REQUIRE_INIT();
     LG_ARG(!capturing(), "lg_sync: not allowed while capturing a graph");
-    { const int rc = side_join(); if (rc != LG_OK) return rc; }
+    { const int rc = flush_queued(); if (rc != LG_OK) return rc; }
     LG_HIP(hipStreamSynchronize(rt().stream));
     return check_device_status("lg_sync");
 }
@@ -338,10 +262,6 @@ int lg_free(void* ptr) {
     Block b = it->second;
     P.live.erase(it);
     P.in_use -= b.bytes;
-    if (rt().side_dirty) {                 // the other stream may still be using it: parked until lg_side_join
-        P.quarantine.emplace_back(ptr, b);
-        return LG_OK;
-    }
     if (b.graph != 0) {
         // memory a captured graph reads or writes stays pinned to that graph
         auto g = P.graphs.find(b.graph);
@@ -358,7 +278,7 @@ int lg_free(void* ptr) {
 int lg_pool_trim(void) {
     LG_REQUIRE_INIT();
     LG_ARG(!capturing(), "lg_pool_trim: not allowed while capturing a graph");
-    { const int rc = side_join(); if (rc != LG_OK) return rc; }
+    { const int rc = flush_queued(); if (rc != LG_OK) return rc; }
     LG_HIP(hipStreamSynchronize(rt().stream));
     Pool& P = pool();
     std::lock_guard<std::mutex> lock(P.mu);
@@ -430,120 +350,12 @@ int lg_memcpy_h2d_async(void* dst, const void* src, size_t bytes) {
     return LG_OK;
 }
 
-// ---- prefetch on a copy stream ---------------------------------------------------------------------------------
-// The DMA of the NEXT batch runs on its own stream while the compute stream replays the current step:
-//   lg_prefetch_h2d   host -> a device staging slot, on the copy stream (pinned sources are read in place)
-//   lg_prefetch_commit   compute stream waits for that DMA, copies slot -> dst (device to device, microseconds) and
-//                        frees the slot for the next prefetch
-// so a step costs max(DMA, compute) instead of their sum.
-namespace {
-struct PrefetchSlot {
-    void*      dev = nullptr;
-    size_t     capacity = 0, bytes = 0;
-    hipEvent_t copied = nullptr, consumed = nullptr;
-    bool       in_flight = false, consumed_recorded = false;
-};
-constexpr int kPrefetchSlots = 4;
-PrefetchSlot g_prefetch[kPrefetchSlots];
-int g_prefetch_next = 0;
-hipStream_t g_copy_stream = nullptr;
-}  // namespace
-
-int lg_host_malloc(void** ptr, size_t bytes) {
-    LG_REQUIRE_INIT();
-    LG_ARG(ptr != nullptr, "lg_host_malloc: NULL");
-    *ptr = nullptr;
-    if (bytes == 0) return LG_OK;
-    LG_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
-    return LG_OK;
-}
-
-int lg_host_free(void* ptr) {
-    LG_REQUIRE_INIT();
-    if (ptr) LG_HIP(hipHostFree(ptr));
-    return LG_OK;
-}
-
-int lg_prefetch_h2d(const void* src, size_t bytes, int* slot_out) {
-    LG_REQUIRE_INIT();
-    LG_ARG(src != nullptr && slot_out != nullptr && bytes > 0, "lg_prefetch_h2d: bad arguments");
-    if (!g_copy_stream) LG_HIP(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
-    const int slot = g_prefetch_next;
-    PrefetchSlot& ps = g_prefetch[slot];
-    LG_ARG(!ps.in_flight, "lg_prefetch_h2d: all %d prefetch slots are waiting for lg_prefetch_commit", kPrefetchSlots);
-    g_prefetch_next = (g_prefetch_next + 1) % kPrefetchSlots;
-    if (!ps.copied) {
-        LG_HIP(hipEventCreateWithFlags(&ps.copied, hipEventDisableTiming));
-        LG_HIP(hipEventCreateWithFlags(&ps.consumed, hipEventDisableTiming));
-    }
-    if (ps.consumed_recorded) {
-        if (ps.capacity < bytes) LG_HIP(hipEventSynchronize(ps.consumed));      // about to free the buffer
-        else LG_HIP(hipStreamWaitEvent(g_copy_stream, ps.consumed, 0));          // the copy stream waits, not the host
-    }
-    if (ps.capacity < bytes) {
-        if (ps.dev) LG_HIP(hipFree(ps.dev));
-        ps.dev = nullptr;
-        ps.capacity = 0;
-        const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-        LG_HIP(hipMalloc(&ps.dev, want));
-        ps.capacity = want;
-    }
-    // pinned sources are read by the DMA engine in place; pageable ones go through the pinned staging ring
-    hipPointerAttribute_t attr;
-    const void* dma_src = src;
-    const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (!pinned) {
-        (void)hipGetLastError();
-        Staging& st = g_staging[g_staging_next];
-        g_staging_next = (g_staging_next + 1) % kStagingSlots;
-        if (st.busy) {
-            LG_HIP(hipEventSynchronize(st.done));
-            st.busy = false;
-        }
-        if (st.bytes < bytes) {
-            if (st.host) LG_HIP(hipHostFree(st.host));
-            st.host = nullptr;
-            st.bytes = 0;
-            const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-            LG_HIP(hipHostMalloc(&st.host, want, hipHostMallocDefault));
-            st.bytes = want;
-        }
-        if (!st.done) LG_HIP(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
-        memcpy(st.host, src, bytes);
-        dma_src = st.host;
-        LG_HIP(hipMemcpyAsync(ps.dev, dma_src, bytes, hipMemcpyHostToDevice, g_copy_stream));
-        LG_HIP(hipEventRecord(st.done, g_copy_stream));
-        st.busy = true;
-    } else {
-        LG_HIP(hipMemcpyAsync(ps.dev, dma_src, bytes, hipMemcpyHostToDevice, g_copy_stream));
-    }
-    LG_HIP(hipEventRecord(ps.copied, g_copy_stream));
-    ps.bytes = bytes;
-    ps.in_flight = true;
-    *slot_out = slot;
-    return LG_OK;
-}
-
-int lg_prefetch_commit(int slot, void* dst, size_t bytes) {
-    LG_REQUIRE_INIT();
-    LG_ARG(slot >= 0 && slot < kPrefetchSlots && dst != nullptr, "lg_prefetch_commit: bad slot / destination");
-    LG_ARG(!capturing(), "lg_prefetch_commit: not allowed while capturing a graph (commit between graph launches)");
-    PrefetchSlot& ps = g_prefetch[slot];
-    LG_ARG(ps.in_flight && ps.bytes == bytes, "lg_prefetch_commit: slot %d holds no prefetch of %zu bytes", slot, bytes);
-    LG_HIP(hipStreamWaitEvent(rt().stream, ps.copied, 0));
-    LG_HIP(hipMemcpyAsync(dst, ps.dev, bytes, hipMemcpyDeviceToDevice, rt().stream));
-    LG_HIP(hipEventRecord(ps.consumed, rt().stream));
-    ps.consumed_recorded = true;
-    ps.in_flight = false;
-    return LG_OK;
-}
-
 int lg_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     LG_REQUIRE_INIT();
     if (bytes == 0) return LG_OK;
     LG_ARG(dst && src, "lg_memcpy_d2h: NULL pointer");
     LG_ARG(!capturing(), "lg_memcpy_d2h: host transfers cannot be captured");
-    { const int rc = side_join(); if (rc != LG_OK) return rc; }        // the bytes may come from the side stream
+    { const int rc = flush_queued(); if (rc != LG_OK) return rc; }
     LG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, rt().stream));
     LG_HIP(hipStreamSynchronize(rt().stream));
     return check_device_status("lg_memcpy_d2h");
@@ -593,11 +405,10 @@ int lg_event_destroy(void* ev) {
 
 int lg_graph_begin(void) {
     LG_REQUIRE_INIT();
-    if (!rt().side_open) { const int rc = side_join(); if (rc != LG_OK) return rc; }
+    { const int rc = flush_queued(); if (rc != LG_OK) return rc; }
     Pool& P = pool();
     std::lock_guard<std::mutex> lock(P.mu);
     LG_ARG(P.capture == nullptr, "lg_graph_begin: a capture is already in progress");
-    LG_ARG(!rt().side_open && !rt().side_dirty, "lg_graph_begin: side-stream work is pending (lg_side_join first)");
     // relaxed mode: hipMalloc from the pool is legal while capturing
     LG_HIP(hipStreamBeginCapture(rt().stream, hipStreamCaptureModeRelaxed));
     GraphRec* g = new GraphRec();
@@ -610,8 +421,7 @@ int lg_graph_begin(void) {
 int lg_graph_end(void** graph_exec) {
     LG_REQUIRE_INIT();
     LG_ARG(graph_exec != nullptr, "lg_graph_end: NULL");
-    if (rt().side_open) (void)lg_side_end();
-    (void)side_join();                   // a captured side branch must flow back into the main stream before the capture ends
+    (void)flush_queued();                // queued launches belong to the capture that queued them
     Pool& P = pool();
     std::lock_guard<std::mutex> lock(P.mu);
     LG_ARG(P.capture != nullptr, "lg_graph_end: no capture in progress");
@@ -637,7 +447,7 @@ int lg_graph_launch(void* graph_exec) {
     LG_REQUIRE_INIT();
     LG_ARG(graph_exec != nullptr, "lg_graph_launch: NULL");
     LG_ARG(!capturing(), "lg_graph_launch: not allowed while capturing");
-    { const int rc = side_join(); if (rc != LG_OK) return rc; }
+    { const int rc = flush_queued(); if (rc != LG_OK) return rc; }
     GraphRec* g = static_cast<GraphRec*>(graph_exec);
     LG_HIP(hipGraphLaunch(g->exec, rt().stream));
     return LG_OK;

@@ -95,7 +95,9 @@ class Adam(Optimizer):
         self._flat_grad = flat_grads
         self._flat = (flat_params, cls.zeros(flat_params.shape, requires_grad=False),
                       cls.zeros(flat_params.shape, requires_grad=False), tuple(int(o) for o in offsets))
-        self._step_counter = flat_params._new_step_counter(0)
+        # the update launch advances the device step number itself: one private copy per workgroup of its grid
+        longest = max(b - a for a, b in zip(self._flat[3][:-1], self._flat[3][1:]))
+        self._step_counter = flat_params._new_step_counter(0, slots=max(1, len(self.parameters) * -(-longest // 1024)))
 
     def use_peer_exchange(self, comm) -> None:
         """data parallel with a communicator whose exchange rides in the optimizer launch (dist.PeerWindowCommunicator):
@@ -138,7 +140,7 @@ class Adam(Optimizer):
                 kernel(p.grad, self.m[i], self.v[i], self.lr, self.b1, self.b2, self.eps,
                        (1 - self.b1**self.t) ** -1, (1 - self.b2**self.t) ** -1, self.grad_scale, self.belief)
         if self._step_counter is not None:
-            self.parameters[0]._advance_step_counter(self._step_counter, defer=True)
+            self.parameters[0]._advance_step_counter(self._step_counter)      # these kernels only read the counter: one tiny launch
 
     def on_graph_replay(self, n: int = 1) -> None:
         """keep the host-side step count in line after `n` replays of a captured step"""

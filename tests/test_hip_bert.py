@@ -211,15 +211,13 @@ def test_parameter_gradients_accumulate_in_place(hip):
     np.testing.assert_allclose(2 * tt.grad.numpy(), ct.grad.numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("how", ["group", "side_stream"])
-def test_parameter_gradients_off_the_critical_path(hip, how):
+def test_parameter_gradients_off_the_critical_path(hip):
     """a deep tape queues dW / db and LayerNorm's parameter gradients and launches them together at the end of the pass
-    (autograd/hip/tensor.py GradGroup, the default) or - on request - sends them to a second stream (SideStream): same
-    gradients as the plain single-stream pass - eager, accumulated over two passes, and replayed from a hipGraph - and no
-    memory stays parked afterwards"""
+    (autograd/hip/tensor.py GradGroup): same gradients as the plain pass - eager, accumulated over two passes, and replayed
+    from a hipGraph - and no memory stays parked afterwards"""
     import gc
     from lightgrad_amd.autograd.hip import HipGraph, HipDevice
-    from lightgrad_amd.autograd.hip.tensor import GradGroup, SideStream
+    from lightgrad_amd.autograd.hip.tensor import GradGroup
     from lightgrad_amd.dist import DataParallel, SingleProcess
     rng = np.random.RandomState(5)
     ids_np = rng.randint(0, 300, (4, 32)).astype(np.int32)
@@ -241,10 +239,9 @@ def test_parameter_gradients_off_the_critical_path(hip, how):
         return loss
 
     def configure(on):
-        GradGroup.enabled = on and how == "group"
-        SideStream.enabled = on and how == "side_stream"
+        GradGroup.enabled = on
 
-    defaults = (GradGroup.enabled, SideStream.enabled)
+    default = GradGroup.enabled
     try:
         results = {}
         for mode in (False, True):
@@ -257,7 +254,7 @@ def test_parameter_gradients_off_the_critical_path(hip, how):
         assert np.abs(results[True][0]).max() > 0
         for a, b in zip(results[True], results[False]):
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * np.abs(b).max())
-        # captured (the side brackets become branches of the graph): every replay gives the eager gradients again
+        # captured: every replay gives the eager gradients again
         configure(True)
         model, dp = build()
         one_pass(model, dp)
@@ -279,7 +276,7 @@ def test_parameter_gradients_off_the_critical_path(hip, how):
             in_use.append(HipDevice.pool_stats()["in_use_bytes"])
         assert in_use[2] == in_use[1], in_use                     # nothing stays parked or leaks per pass
     finally:
-        GradGroup.enabled, SideStream.enabled = defaults
+        GradGroup.enabled = default
 
 
 def test_bert_training_steps_replayed_from_a_graph_match_the_eager_tape(hip):

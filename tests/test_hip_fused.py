@@ -317,24 +317,35 @@ def test_multi_tensor_adam_beyond_64_parameters(hip):
     total = offsets[-1]
     p0, g0 = rng.uniform(-1, 1, total).astype(np.float32), rng.uniform(-1, 1, total).astype(np.float32)
     results = []
-    for flat in (True, False):
+    slots = len(sizes) * 1                    # every parameter is shorter than 1024: one workgroup (and one step slot) each
+    for form in ("flat_own_step_slots", "flat_shared_counter", "per_parameter"):
         p, g = hip.from_numpy(p0.copy(), requires_grad=False), hip.from_numpy(g0.copy(), requires_grad=False)
         m, v = hip.zeros((total,), requires_grad=False), hip.zeros((total,), requires_grad=False)
-        counter = hip.from_numpy(np.asarray([3, 0], np.int64), requires_grad=False)
+        counter = hip.from_numpy(np.asarray([3, 0] + [3] * slots, np.int64), requires_grad=False)
         for _ in range(2):
-            if flat:
+            if form == "flat_own_step_slots":          # the launch advances the step itself (private copy per workgroup)
                 L.check(lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, len(sizes), L.i64(offsets), 1e-2, 0.9, 0.999, 1e-8,
-                                                  counter.ptr, 0.5, 1, 0))
+                                                  counter.ptr, slots, 0.5, 1))
+                continue
+            if form == "flat_shared_counter":
+                L.check(lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, len(sizes), L.i64(offsets), 1e-2, 0.9, 0.999, 1e-8,
+                                                  counter.ptr, 0, 0.5, 1))
             else:
                 for j, n in enumerate(sizes):
                     o = offsets[j] * 4
                     L.check(lib.lg_adam_step_dev_f32(p.ptr + o, g.ptr + o, m.ptr + o, v.ptr + o, n, 1e-2, 0.9, 0.999, 1e-8,
                                                      counter.ptr, len(sizes), j + 1, 0.5, 1))
             L.check(lib.lg_counter_add_i64(counter.ptr, 1))
+        c = counter.numpy()
+        assert c[0] == 5 and (form != "flat_own_step_slots" or np.all(c[2:] == 5)), c[:8]
         results.append((p.numpy(), m.numpy(), v.numpy()))
-    for a, b in zip(*results):
-        np.testing.assert_array_equal(a, b)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            np.testing.assert_array_equal(a, b)
     assert np.abs(results[0][0] - p0).max() > 1e-3
+    # too few step slots for the launch grid is an argument error, not a scribble
+    assert lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, len(sizes), L.i64(offsets), 1e-2, 0.9, 0.999, 1e-8, counter.ptr, 10, 0.5, 1) == -1
+    assert b"step slots" in lib.lg_last_error()
 
 
 def test_bias_free_linear_waits_for_its_bias_row(hip):
@@ -493,3 +504,49 @@ def test_linear_with_residual_and_gradients_accumulated_in_the_input_product(hip
     fused = H._gemm(hip.from_numpy(a), H._swap_last(hip.from_numpy(w)), bias=hip.from_numpy(bias), addend=hip.from_numpy(r))
     plain = H._gemm(hip.from_numpy(a), H._swap_last(hip.from_numpy(w)), bias=hip.from_numpy(bias)) + hip.from_numpy(r)
     np.testing.assert_array_equal(fused.numpy(), plain.numpy())
+
+
+def test_tied_table_looked_up_twice_keeps_call_order_in_the_gradient_queues(hip):
+    """A weight used as an embedding table (looked up TWICE) and as the output projection, on a tape deep enough for the
+    gradient group (>= 48 nodes), after a flat-bucket zero_grad: the projection's dW is queued as an OVERWRITING product, the
+    two scatter-adds are queued behind it - and the second one (same table) forces an early flush of its queue.  The products
+    must leave first (round 2 launched the first scatter-add ahead of the overwrite and lost it).  Against the CPU backend."""
+    from lightgrad_amd import nn, CpuTensor
+    from lightgrad_amd.dist import DataParallel, SingleProcess
+    rng = np.random.RandomState(3)
+    vocab, width, rows = 40, 16, 12
+    w0 = (rng.uniform(-1, 1, (vocab, width)) / 4).astype(np.float32)
+    ids1, ids2 = rng.permutation(vocab)[:rows].astype(np.int32), rng.permutation(vocab)[:rows].astype(np.int32)      # unique per lookup
+    target = rng.uniform(0, 1, (rows, vocab)).astype(np.float32)
+
+    class Tied(nn.Module):
+        def __init__(self):
+            nn.Module.__init__(self)
+            self.out = nn.Linear(width, vocab, bias=False)
+
+        def forward(self, a, b):
+            table = self.out.weight
+            h = table[a] + table[b]
+            for _ in range(26):
+                h = h * 1.0 + 0.0                       # 52 more tape nodes
+            return self.out(h)
+
+    grads = {}
+    for cls in (CpuTensor, hip):
+        model = Tied()
+        model.load_parameters({"out.weight": w0})
+        if cls is hip:
+            model.map_parameters(lambda p: p.hip())
+            opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=True, device_step=True)
+            DataParallel(model.parameters(), SingleProcess(), flatten=True).attach(opt)
+        else:
+            opt = light.optim.AdaBelief(model.parameters(), lr=1e-3)
+        a, b, t = (cls.from_numpy(v, requires_grad=False) for v in (ids1, ids2, target))
+        for _ in range(2):                              # the second pass starts from zero-PENDING gradients on the device
+            loss = light.loss.mse(model(a, b), t)
+            opt.zero_grad()
+            loss.backward()
+        grads[cls] = model.out.weight.grad.numpy().copy()
+    scale = np.abs(grads[CpuTensor]).max()
+    np.testing.assert_allclose(grads[hip], grads[CpuTensor], rtol=1e-5, atol=1e-6 * scale)
+    assert np.abs(grads[CpuTensor][ids1]).max() > 0

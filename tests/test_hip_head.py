@@ -32,10 +32,8 @@ def test_head_forward_c_abi(hip, rows, hidden, outs, relu, with_bias):
     t = rng.uniform(0, 1, (rows, outs)).astype(np.float32)
     tx, tw, tb, tt = (hip.from_numpy(a, requires_grad=False) for a in (x, w, b, t))
     y, err, row_loss, loss = hip.empty((rows, outs)), hip.empty((rows, outs)), hip.empty((rows,)), hip.empty(())
-    counter = hip.from_numpy(np.asarray([41, 0], np.int64), requires_grad=False)
-    for use_counter in (False, True):
-        L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, relu, tw.ptr, tb.ptr if with_bias else None, tt.ptr, y.ptr, err.ptr, row_loss.ptr,
-                                    rows, hidden, outs, counter.ptr if use_counter else None))
+    L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, relu, tw.ptr, tb.ptr if with_bias else None, tt.ptr, y.ptr, err.ptr, row_loss.ptr,
+                                rows, hidden, outs))
     L.check(lib.lg_mse_finalize_f32(row_loss.ptr, rows, rows * outs, loss.ptr))
     a64 = (_relu(x) if relu else x).astype(np.float64)
     y_ref = a64 @ w.astype(np.float64).T + (b if with_bias else 0)
@@ -43,13 +41,12 @@ def test_head_forward_c_abi(hip, rows, hidden, outs, relu, with_bias):
     np.testing.assert_allclose(y.numpy(), y_ref, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(err.numpy(), e_ref, rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(loss.item(), (e_ref ** 2).mean() / 2, rtol=1e-5)
-    np.testing.assert_array_equal(counter.numpy(), [42, 0])             # advanced exactly once, by the launch that was given it
     # err is exactly y + (-target) of the y that was written (one rounding, like the tape's `y - y_hat`)
     np.testing.assert_array_equal(err.numpy(), y.numpy() + (-t))
     # bit-reproducible from launch to launch
     first = (y.numpy().copy(), loss.numpy().copy())
     L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, relu, tw.ptr, tb.ptr if with_bias else None, tt.ptr, y.ptr, err.ptr, row_loss.ptr,
-                                rows, hidden, outs, None))
+                                rows, hidden, outs))
     L.check(lib.lg_mse_finalize_f32(row_loss.ptr, rows, rows * outs, loss.ptr))
     np.testing.assert_array_equal(y.numpy(), first[0])
     np.testing.assert_array_equal(loss.numpy(), first[1])
@@ -105,10 +102,10 @@ def test_head_c_abi_rejects_what_it_cannot_do(hip):
     from lightgrad_amd.autograd.hip import lib as L
     lib = L.lib()
     t = hip.zeros((8, 8), requires_grad=False)
-    assert lib.lg_head_fwd_f32(t.ptr, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 8, 17, None) != 0          # > 16 outputs
+    assert lib.lg_head_fwd_f32(t.ptr, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 8, 17) != 0          # > 16 outputs
     assert b"outs" in lib.lg_last_error()
-    assert lib.lg_head_fwd_f32(t.ptr, 6, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 6, 4, None) != 0           # hidden % 4
-    assert lib.lg_head_fwd_f32(t.ptr + 4, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 7, 8, 4, None) != 0       # misaligned x
+    assert lib.lg_head_fwd_f32(t.ptr, 6, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 8, 6, 4) != 0           # hidden % 4
+    assert lib.lg_head_fwd_f32(t.ptr + 4, 8, 0, t.ptr, None, t.ptr, t.ptr, t.ptr, t.ptr, 7, 8, 4) != 0       # misaligned x
     assert lib.lg_head_bwd_f32(t.ptr, 8, 0, t.ptr, t.ptr, t.ptr, t.ptr, None, 0, None, 0, 8, 8, 4, None, None) != 0   # gpre without relu
     assert lib.lg_head_bwd_f32(None, 8, 0, t.ptr, t.ptr, None, None, None, 0, None, 0, 8, 8, 4, None, None) != 0
 
@@ -219,31 +216,31 @@ def test_step_counter_rides_in_the_loss_kernel(hip, loss_kind):
             if loss_kind == "head":
                 loss = light.loss.mse(y, t)
             elif loss_kind == "plain_mse":
-                loss = light.loss.mse(y * 1.0, t)                        # y is materialised by the multiplication: lg_mse_bump_f32
+                loss = light.loss.mse(y * 1.0, t)                        # y is materialised by the multiplication: lg_mse_f32
             else:
                 loss = ((y - t) ** 2).mean()                             # no fused loss at all: the optimizer flushes
             opt.zero_grad()
             loss.backward()
             opt.step()
             if device_step:
-                assert len(HipTensor._waiting_step_counters()) == 1
                 with light.no_grad():
                     light.loss.mse(model(x), t)                          # evaluation pass: must not advance anything
-                assert len(HipTensor._waiting_step_counters()) == 1
                 c = opt._step_counter.numpy()[0]
-                assert c == step, (c, step)                              # the "+1" of this step is still waiting
+                assert c == step + 1, (c, step)                          # advanced by the optimizer step itself
         finals.append([p.numpy() for p in model.parameters()])
         if device_step:
-            HipTensor._flush_step_counter(opt._step_counter)
-            assert opt._step_counter.numpy()[0] == 4 and not HipTensor._waiting_step_counters()
+            assert opt._step_counter.numpy()[0] == 4
     for a, b in zip(*finals):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("scenario", ["warm_whole_step", "nothing_waiting_at_capture", "no_carrier_in_graph", "graph_fwd_bwd_eager_optimizer",
-                                      "capture_then_eager", "three_steps_per_graph", "three_steps_per_graph_no_carrier"])
-def test_step_counter_stays_right_across_graph_capture(hip, scenario):
-    """one increment of the device step counter per training step, whatever mix of eager steps, captures and replays:
+@pytest.mark.parametrize("flat", [False, True], ids=["per_parameter_kernels", "flat_bucket_one_launch"])
+@pytest.mark.parametrize("scenario", ["warm_whole_step", "unfused_loss_in_graph", "graph_fwd_bwd_eager_optimizer",
+                                      "separate_graphs_fwd_bwd_first", "separate_graphs_optimizer_first",
+                                      "capture_then_eager", "three_steps_per_graph", "three_steps_per_graph_unfused_loss"])
+def test_step_counter_stays_right_across_graph_capture(hip, scenario, flat):
+    """one increment of the device step counter per training step, whatever mix of eager steps, captures and replays - also
+    with forward+backward and the optimizer in two SEPARATE graphs (round 2's carried increment counted twice there):
     the weights after 7 steps must equal those of the host-scalar optimizer (its bias corrections depend on the step)"""
     from lightgrad_amd.autograd.hip import HipGraph, HipTensor
     import gc
@@ -257,11 +254,14 @@ def test_step_counter_stays_right_across_graph_capture(hip, scenario):
         np.random.seed(1)
         model = MLP(12, 8, 4).map_parameters(lambda p: p.hip())
         opt = light.optim.AdaBelief(model.parameters(), lr=1e-2, fused=True, device_step=device_step)
+        if flat and device_step:
+            from lightgrad_amd.dist import DataParallel, SingleProcess
+            DataParallel(model.parameters(), SingleProcess(), flatten=True).attach(opt)
         x, t = hip.from_numpy(xn), hip.from_numpy(tn, requires_grad=False)
 
         def fwd_bwd():
             y = model(x)
-            loss = ((y - t) ** 2).mean() if "no_carrier" in scenario else light.loss.mse(y, t)
+            loss = ((y - t) ** 2).mean() if "unfused_loss" in scenario else light.loss.mse(y, t)
             opt.zero_grad()
             loss.backward()
             return loss
@@ -282,11 +282,26 @@ def test_step_counter_stays_right_across_graph_capture(hip, scenario):
     for _ in range(2):
         step()
     done = 2
-    if scenario == "nothing_waiting_at_capture":
-        HipTensor._flush_step_counter(opt._step_counter)                 # e.g. an optimizer whose last step ran long ago
-        assert not HipTensor._waiting_step_counters()
-    g = HipGraph()
-    if scenario == "graph_fwd_bwd_eager_optimizer":
+    g, g2 = HipGraph(), HipGraph()
+    if scenario.startswith("separate_graphs"):
+        if scenario.endswith("optimizer_first"):
+            fwd_bwd()                                                    # gradients for the optimizer capture to read
+            with g2.capture():
+                opt.step()
+            with g.capture():
+                fwd_bwd()
+        else:
+            with g.capture():
+                fwd_bwd()
+            with g2.capture():
+                opt.step()
+        opt.t -= n_params
+        while done < total:
+            g.replay()
+            g2.replay()
+            opt.on_graph_replay()
+            done += 1
+    elif scenario == "graph_fwd_bwd_eager_optimizer":
         with g.capture():
             fwd_bwd()
         while done < total:
@@ -320,11 +335,12 @@ def test_step_counter_stays_right_across_graph_capture(hip, scenario):
             g.replay()
             opt.on_graph_replay()
             done += 1
-    HipTensor._flush_step_counter(opt._step_counter)
     assert opt._step_counter.numpy()[0] == total
+    assert opt.t == total * n_params
     for a, b in zip([p.numpy() for p in model.parameters()], want):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
     g.destroy()
+    g2.destroy()
 
 
 def test_loss_read_before_backward_equals_loss_finished_by_backward(hip):

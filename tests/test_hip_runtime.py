@@ -125,50 +125,31 @@ def test_c_abi_argument_checks(hip):
     assert lib.lg_copy_strided(3, 2, sh, t.ptr, st, t.ptr, st) == -1                                              # itemsize 3
     assert lib.lg_softmax_f32(t.ptr, t.ptr, 4, 0) == -1
     assert lib.lg_gather_rows_f32(t.ptr, t.ptr, 2, t.ptr, 1, 4, 4) == -1                                          # int16 ids
-    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 0, L.i64((0,)), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == -1        # no segments
-    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 65, L.i64((0,) * 66), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == 0    # 65 EMPTY segments: two groups, nothing to do
-    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 2, L.i64((0, 8, 4)), 1e-3, .9, .999, 1e-8, t.ptr, 1.0, 1, 0) == -1    # decreasing offsets
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 0, L.i64((0,)), 1e-3, .9, .999, 1e-8, t.ptr, 0, 1.0, 1) == -1        # no segments
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 65, L.i64((0,) * 66), 1e-3, .9, .999, 1e-8, t.ptr, 0, 1.0, 1) == 0    # 65 EMPTY segments: two groups, nothing to do
+    assert lib.lg_adam_multi_dev_f32(t.ptr, t.ptr, t.ptr, t.ptr, 2, L.i64((0, 8, 4)), 1e-3, .9, .999, 1e-8, t.ptr, 0, 1.0, 1) == -1    # decreasing offsets
     ev = ctypes.c_void_p()
     assert lib.lg_event_create(ctypes.byref(ev)) == 0 and lib.lg_event_record(ev) == 0 and lib.lg_event_destroy(ev) == 0
     np.testing.assert_array_equal(t.numpy(), np.zeros((4, 4), np.float32))                                        # nothing was written
 
 
-def test_prefetch_on_the_copy_stream_and_pinned_memory(hip):
-    """HipTensor.prefetch / commit_: pageable and pinned sources, more prefetches than slots over time, values intact
-    when compute keeps the stream busy between prefetch and commit, and the graph-replay usage pattern"""
-    from lightgrad_amd.autograd.hip import HipDevice, HipGraph
+def test_upload_between_graph_replays(hip):
+    """HipTensor.upload_ (lg_memcpy_h2d_async): new batches fed into the static inputs of a captured step between replays; the
+    source array may be reused at once"""
+    from lightgrad_amd.autograd.hip import HipGraph
     rng = np.random.RandomState(0)
-    dst = hip.zeros((257, 129), requires_grad=False)
-    busy = hip.from_numpy(rng.uniform(-1, 1, (512, 512)).astype(np.float32), requires_grad=False)
-    pinned = HipDevice.pinned_empty((257, 129))
-    for i in range(11):
-        a = rng.uniform(-1, 1, (257, 129)).astype(np.float32)
-        if i % 2:
-            pinned[...] = a
-            pending = hip.prefetch(pinned)
-        else:
-            pending = hip.prefetch(a)
-        for _ in range(3):
-            busy = busy @ busy * 1e-2
-        dst.commit_(pending)
-        np.testing.assert_array_equal(dst.numpy(), a)
-        with pytest.raises(AssertionError):
-            dst.commit_(pending)                                   # a prefetch is consumed once
-    # two prefetches in flight (inputs and targets), refreshed between replays of a captured step
     x, t = hip.zeros((64, 32), requires_grad=False), hip.zeros((64, 1), requires_grad=False)
-    out = hip.zeros((1,), requires_grad=False)
     g = HipGraph()
     (x * t).sum()                                                  # warm-up
     with g.capture():
         res = (x * t).sum()
-    batches = [(rng.uniform(-1, 1, (64, 32)).astype(np.float32), rng.uniform(-1, 1, (64, 1)).astype(np.float32)) for _ in range(6)]
-    nxt = (hip.prefetch(batches[0][0]), hip.prefetch(batches[0][1]))
-    for i, (bx, bt) in enumerate(batches):
-        x.commit_(nxt[0])
-        t.commit_(nxt[1])
-        if i + 1 < len(batches):
-            nxt = (hip.prefetch(batches[i + 1][0]), hip.prefetch(batches[i + 1][1]))
+    scratch_x, scratch_t = np.empty((64, 32), np.float32), np.empty((64, 1), np.float32)
+    for _ in range(6):
+        bx, bt = rng.uniform(-1, 1, (64, 32)).astype(np.float32), rng.uniform(-1, 1, (64, 1)).astype(np.float32)
+        scratch_x[...], scratch_t[...] = bx, bt
+        x.upload_(scratch_x)
+        t.upload_(scratch_t)
+        scratch_x[...] = 7.0                                       # staged: the upload no longer reads the source
         g.replay()
         np.testing.assert_allclose(res.item(), float((bx.astype(np.float64) * bt).sum()), rtol=1e-4, atol=1e-4)
     g.destroy()
-    del out

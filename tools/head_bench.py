@@ -33,7 +33,7 @@ def timed(fn, n=200):
     return 1e3 * ms.value / n
 
 
-fwd = lambda: L.check(lib.lg_head_fwd_f32(x.ptr, hidden, 1, w.ptr, b.ptr, tgt.ptr, y.ptr, err.ptr, row_loss.ptr, rows, hidden, outs, None))   # noqa: E731
+fwd = lambda: L.check(lib.lg_head_fwd_f32(x.ptr, hidden, 1, w.ptr, b.ptr, tgt.ptr, y.ptr, err.ptr, row_loss.ptr, rows, hidden, outs))   # noqa: E731
 bwd = lambda: L.check(lib.lg_head_bwd_f32(x.ptr, hidden, 1, g.ptr, w.ptr, dx.ptr, gpre.ptr, dw.ptr, 0, db.ptr, 0, rows, hidden, outs, row_loss.ptr, loss.ptr))    # noqa: E731
 empty = lambda: L.check(lib.lg_counter_add_i64(HipTensor._new_step_counter(0).ptr if False else cnt.ptr, 1))                              # noqa: E731
 cnt = HipTensor.from_numpy(np.zeros(2, np.int64), requires_grad=False)

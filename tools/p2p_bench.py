@@ -40,12 +40,12 @@ def rank_main():
     v = HipTensor.from_numpy(np.abs(v.numpy()), requires_grad=False)
     g = HipTensor.from_numpy(rng.uniform(-1e-3, 1e-3, n).astype(np.float32), requires_grad=False)
     chunks = sum(-(-(b - a) // 1024) for a, b in zip(offsets[:-1], offsets[1:]))
-    step_plain = HipTensor._new_step_counter(0)
+    step_plain = HipTensor._new_step_counter(0, slots=4 * 392)
     step_fused = HipTensor._new_step_counter(0, slots=chunks)
     off = L.i64(offsets)
 
     def plain():
-        L.check(lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, 4, off, 1e-3, 0.9, 0.999, 1e-8, step_plain.ptr, 0.5, 1, 0))
+        L.check(lib.lg_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, 4, off, 1e-3, 0.9, 0.999, 1e-8, step_plain.ptr, 4 * 392, 0.5, 1))
 
     def fused():
         L.check(lib.lg_p2p_adam_multi_dev_f32(p.ptr, g.ptr, m.ptr, v.ptr, 4, off, 1e-3, 0.9, 0.999, 1e-8, step_fused.ptr, chunks, 0.5, 1))

@@ -379,6 +379,18 @@ def gpu_rank(args, rank, world):
             assert abs(dmax + dmin) <= 1e-6 * abs(dmax), "replicas diverged: %r" % ((dmax, -dmin),)
         if quick:
             return dict(steps_per_s=steps_per_s)
+        # `value` covers exactly --steps steps; with few steps the two fences and the first launch weigh on it (20 steps = 1.2 ms:
+        # -6 %), so the same loop is also timed over >= 0.1 s and reported NEXT to it (`value_long_window`), never as `value`
+        long_window = None
+        if use_graph and n_steps * (1.0 / steps_per_s * world) < 0.1:
+            reps = max(1, int(0.12 * steps_per_s / world / max(1, unroll)))
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                (g_multi if unroll > 1 else g_all).replay()
+            opt.on_graph_replay(reps * unroll)
+            fence()
+            long_window = {"steps": reps * unroll, "steps_per_sec": round(world * reps * unroll / wall_max(time.perf_counter() - t0), 2)}
 
         # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
         eager_steps = max(10, min(args.steps, 100))
@@ -390,6 +402,15 @@ def gpu_rank(args, rank, world):
             eager_step()
         fence()
         eager_steps_per_s = world * eager_steps / wall_max(time.perf_counter() - t0)
+        # the launch-bound step's honest bound is host dispatch - tape nodes (Function calls) and kernel launches
+        # of one eager step, counted by the profiler hooks of the tape and by the pool of a 1-step capture
+        from lightgrad_amd.autograd.utils.profiler import Profiler
+        with Profiler() as prof:
+            eager_step()
+        launches_per_step = None
+        if use_graph:
+            launches_per_step = g_all.kernel_count() if g_all is not None else g_fb.kernel_count() + 2      # + host-launched all-reduce and optimizer
+        dispatched_ops = int(sum(fc + bc for _, fc, _, bc in prof.table().values()))      # outermost Function calls, forward + backward
 
         # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
         # computes and drops, is then not computed at all.  Reported next to `value`, never as `value`.
@@ -419,7 +440,7 @@ def gpu_rank(args, rank, world):
             data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
             opt.on_graph_replay(args.warmup + args.steps)
         return dict(steps_per_s=steps_per_s, elapsed=elapsed, per_rank=per_rank, final_loss=final_loss, first_losses=first_losses,
-                    eager_steps_per_s=eager_steps_per_s, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
+                    eager_steps_per_s=eager_steps_per_s, dispatched_ops=dispatched_ops, launches_per_step=launches_per_step, long_window=long_window, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
                     unroll=unroll, use_graph=use_graph, overlap=dp.overlap, w0=w0, x_np=x_np, onehot_np=onehot_np)
 
     def assemble(R, chosen, calibration, fallback_reason, extra):
@@ -457,8 +478,14 @@ def gpu_rank(args, rank, world):
             "final_loss": round(R["final_loss"], 6),
             "first_losses": [round(v, 7) for v in R["first_losses"]],
             "ranks": ranks_info,
+            "value_long_window": R["long_window"],
             "mlp_gemm_tflops": round(R["steps_per_s"] * MLP_GEMM_FLOP / 1e12, 3),
             "mlp_steps_per_sec_eager": round(R["eager_steps_per_s"], 2),
+            # the launch-bound step, per dispatched op - tape dispatches (outermost Function forward / backward calls +
+            # the optimizer) of one eager step, the kernel launches they turn into, and the host time per dispatch of the eager tape
+            "dispatch": {"tape_dispatches_per_step": R["dispatched_ops"], "launches_per_step": R["launches_per_step"],
+                         "us_per_dispatched_op_eager": round(1e6 / R["eager_steps_per_s"] * world / max(1, R["dispatched_ops"]), 2),
+                         "us_per_launch_replayed": round(1e6 / R["steps_per_s"] * world / max(1, R["launches_per_step"]), 2) if R["launches_per_step"] else None},
             "mlp_steps_per_sec_batch_as_data": None if R["data_input_steps_per_s"] is None else round(R["data_input_steps_per_s"], 2),
         }
         out.update(extra)
@@ -645,11 +672,31 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
         for t in ins + [None] * (4 - len(ins)):
             args_ += [t.ptr if t is not None else None, st if t is not None else None]
         return lambda: L.check(lib.lg_ew(op, 2, sh, out.ptr, st, None, None, *args_, 0.0))
+    from lightgrad_amd.autograd.hip import ops as H
+    bias_row = HipTensor.from_numpy(np.random.RandomState(3).uniform(-1, 1, (big[1],)).astype(np.float32), requires_grad=False)
+    with light.no_grad():
+        rowmax = p.max(axis=1, keepdims=True)
     for name, fn, bytes_per_elem in [("add", ew(L.EW_ADD, r, [p, q]), 12), ("mul", ew(L.EW_MUL, r, [p, q]), 12),
                                      ("relu", ew(L.EW_RELU, r, [p]), 8), ("exp", ew(L.EW_EXP, r, [p]), 8),
-                                     ("relu_bwd", ew(L.EW_RELU_BWD, r, [p, q]), 12), ("iadd", ew(L.EW_ADD, r, [r, q]), 12)]:
+                                     ("relu_bwd", ew(L.EW_RELU_BWD, r, [p, q]), 12), ("iadd", ew(L.EW_ADD, r, [r, q]), 12),
+                                     # backward forms and strided / broadcast operands, through the ops' own entry points
+                                     ("exp_bwd  y*g", lambda: H._binary(L.EW_MUL, p, q, out=r), 12),
+                                     ("mul_bwd  (g*b, a*g)", lambda: H._ew(L.EW_MUL_BWD, big, [p, q, r], n_out=2), 20),
+                                     ("max_bwd  g*(x==max) axis=1", lambda: H._ew(L.EW_MAX_BWD, big, [p, rowmax, rowmax], out=r), 8),
+                                     ("add_bias (N,C)+(C,)", lambda: H._binary(L.EW_ADD, p, bias_row, out=r), 8)]:
         ms = time_launches(fn, 5)
         hbm[name] = {"ms": round(ms, 4), "GB/s": round(nbig * bytes_per_elem / (ms * 1e-3) / 1e9, 1)}
+    del rowmax
+    # transposed operands at 8192^2 (256 MiB per tensor): the strided `dW +=` of the reference's tape and a layout change
+    sq = (8192, 8192)
+    ta, tb = p.reshape(2, 8192, 8192)[0], q.reshape(2, 8192, 8192)[0]
+    tout = r.reshape(2, 8192, 8192)[0]
+    for name, fn, nbytes in [("add a + b.T", lambda: H._binary(L.EW_ADD, ta, tb.transpose(1, 0), out=tout), 12 * sq[0] * sq[1]),
+                             ("contiguous(b.T)", lambda: tb.transpose(1, 0).contiguous(), 8 * sq[0] * sq[1])]:
+        with light.no_grad():
+            ms = time_launches(fn, 5)
+        hbm[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1), "shape": "8192x8192"}
+    del ta, tb, tout
     s_out = HipTensor.empty((), requires_grad=False)
     for name, op in [("sum", L.RED_SUM), ("max", L.RED_MAX)]:
         ms = time_launches(lambda: L.check(lib.lg_reduce(op, 2, sh, p.ptr, st, 3, s_out.ptr)), 5)
@@ -663,7 +710,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
     del p, q, r
 
     # ------------------------------------------------------------------ tiny-BERT forward + backward (BASELINE config #5)
-    bert_ms = bert_graph_ms = None
+    bert_ms = bert_graph_ms = bert_launches = None
     bert_replays = 0
     try:
         if args.no_bert:
@@ -700,6 +747,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
         bgraph = HipGraph()
         with bgraph.capture():
             bert_iter()
+        bert_launches = bgraph.kernel_count()
         # 50 timed replays; only 6 with rocprofv3 attached - its HSA queue interceptor faults once a graph's packet batch
         # crosses the end of the 16384-packet AQL ring (evidence: profiles/README.md r2), un-profiled runs never do
         bert_replays = 6 if under_profiler else 50
@@ -733,6 +781,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
                               "config": "2 layers, hidden 128, heads 2, intermediate 512, vocab 30522; masked-LM cross-entropy over all 1024 positions",
                               "dispatch": "eager python tape",
                               "ms_per_iter_hipgraph": round(bert_graph_ms, 3) if bert_graph_ms else None,
+                              "launches_per_iter": bert_launches,
                               "hipgraph_replays_timed": bert_replays, "profiler_attached": under_profiler},
         "roofline": roofline,
         "roofline_hbm": hbm,
@@ -774,8 +823,12 @@ def cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b):
 
     n_all, all_threads, first_losses = tape_loop(8.0, 2000)
     one_thread = n_one = None
+    blas = None
     try:
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import threadpool_limits, threadpool_info
+        blas = [{"library": i.get("internal_api"), "version": i.get("version"), "threads": i.get("num_threads"),
+                 "threading_layer": i.get("threading_layer"), "architecture": i.get("architecture")}
+                for i in threadpool_info() if i.get("user_api") == "blas"]
         with threadpool_limits(limits=1):
             n_one, one_thread, _ = tape_loop(6.0, 2000)
     except Exception:                # threadpoolctl missing or BLAS not controllable: report the all-threads number only
@@ -801,7 +854,7 @@ def cpu_baseline_leg(light, CpuTensor, w0, x_np, onehot_np, a, b):
             "cores": 1 if best_is_one else os.cpu_count(), "kind": "port",
             "what": "lightgrad_amd CpuTensor backend (numpy), same MLP training loop through the python tape",
             "value_all_blas_threads": round(all_threads, 2), "value_one_blas_thread": None if one_thread is None else round(one_thread, 2),
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "blas": blas,
             "sample": "%d steps in ~8 s on all BLAS threads%s; matmul4096 fwd+bwd x1: %.2f s = %.3f TFLOP/s"
                       % (n_all, "" if n_one is None else ", %d steps in ~6 s on one" % n_one, cpu_mm, MATMUL_FLOP / cpu_mm / 1e12),
             "matmul4096_tflops": round(MATMUL_FLOP / cpu_mm / 1e12, 3),

@@ -94,6 +94,7 @@ int lg_graph_begin(void);
 int lg_graph_end(void** graph_exec);
 int lg_graph_launch(void* graph_exec);
 int lg_graph_destroy(void* graph_exec);
+int lg_graph_kernel_count(void* graph, int* kernels);          /* kernel launches one replay performs (reports, tests) */
 
 /* ---- layout ops (bit-exact, any dtype) ----------------------------------- */
 

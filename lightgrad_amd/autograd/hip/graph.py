@@ -50,6 +50,13 @@ class HipGraph(object):
         assert self._exec is not None, "nothing captured"
         _l.check(_l._lib.lg_graph_launch(self._exec))
 
+    def kernel_count(self) -> int:
+        """kernel launches one replay performs"""
+        assert self._exec is not None, "nothing captured"
+        n = ctypes.c_int(0)
+        _l.check(_l._lib.lg_graph_kernel_count(self._exec, ctypes.byref(n)))
+        return n.value
+
     def destroy(self):
         if self._exec is not None and _l._lib is not None:
             _l._lib.lg_graph_destroy(self._exec)

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "lg_graph_end": (c_int, [POINTER(c_void_p)]),
     "lg_graph_launch": (c_int, [c_void_p]),
     "lg_graph_destroy": (c_int, [c_void_p]),
+    "lg_graph_kernel_count": (c_int, [c_void_p, POINTER(c_int)]),
     "lg_copy_strided": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P]),
     "lg_fill_strided": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint64]),
     "lg_ew": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P,

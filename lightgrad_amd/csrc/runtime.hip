@@ -453,6 +453,24 @@ int lg_graph_launch(void* graph_exec) {
     return LG_OK;
 }
 
+int lg_graph_kernel_count(void* graph_exec, int* kernels) {
+    LG_REQUIRE_INIT();
+    LG_ARG(graph_exec != nullptr && kernels != nullptr, "lg_graph_kernel_count: NULL");
+    GraphRec* g = static_cast<GraphRec*>(graph_exec);
+    size_t n = 0;
+    LG_HIP(hipGraphGetNodes(g->graph, nullptr, &n));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n) LG_HIP(hipGraphGetNodes(g->graph, nodes.data(), &n));
+    int count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType type;
+        LG_HIP(hipGraphNodeGetType(nodes[i], &type));
+        if (type == hipGraphNodeTypeKernel) ++count;
+    }
+    *kernels = count;
+    return LG_OK;
+}
+
 int lg_graph_destroy(void* graph_exec) {
     if (!graph_exec) return LG_OK;
     LG_REQUIRE_INIT();

@@ -21,54 +21,62 @@ from .autograd import Gradients, AbstractTensor
 
 
 class Optimizer(object):
+    """A tuple of parameters and the rule that turns a gradient into an additive update.
+
+    Subclasses implement `compute_delta(grad, index)`; `step` adds the result to parameter `index` in place (the `+=` of
+    the parameter's backend, so views handed out earlier keep seeing the parameter)."""
 
     def __init__(self, parameters) -> None:
         self.parameters = tuple(parameters)
-        assert all(isinstance(p, AbstractTensor) for p in self.parameters)
-        self._flat_grad = None
+        strangers = [type(p).__name__ for p in self.parameters if not isinstance(p, AbstractTensor)]
+        assert not strangers, "optimizers update tensors, got %s" % strangers
+        self._flat_grad = None          # the gradient bucket, once a flat-bucket backend took over (use_flat_buckets)
 
     def zero_grad(self) -> None:
-        if self._flat_grad is not None:
-            # every p.grad is a view into the bucket, written by the first backward kernel that reaches it
+        if self._flat_grad is None:
             for p in self.parameters:
-                p._grad_zero_pending = True
+                p.zero_grad()
             return
+        # every p.grad is a view into the bucket, written by the first backward kernel that reaches it
         for p in self.parameters:
-            p.zero_grad()
-
-    @Gradients.no_grad()
-    def step(self) -> None:
-        for i, p in enumerate(self.parameters):
-            p += self.compute_delta(p.grad, i)
+            p._grad_zero_pending = True
 
     def compute_delta(self, grad: AbstractTensor, idx: int) -> AbstractTensor:
-        raise NotImplementedError()
+        raise NotImplementedError("%s does not say how a gradient becomes an update" % type(self).__name__)
+
+    def step(self) -> None:
+        with Gradients.no_grad():
+            for index, parameter in enumerate(self.parameters):
+                parameter += self.compute_delta(parameter.grad, index)
 
 
 class SGD(Optimizer):
-    """ Stochastic Gradient Descent """
+    """gradient descent with (heavy-ball) momentum: the update is -lr * grad plus `momentum` times the previous update"""
 
     def __init__(self, parameters, lr: float, momentum: float = 0.0):
         Optimizer.__init__(self, parameters)
-        self.prev_deltas = [0] * len(self.parameters)
-        self.lr, self.momentum = lr, momentum
+        self.lr = lr
+        self.momentum = momentum
+        self.last_update = {}           # parameter index -> the update applied last (missing: none yet)
 
     def compute_delta(self, grad, i):
-        self.prev_deltas[i] = -self.lr * grad + self.momentum * self.prev_deltas[i]
-        return self.prev_deltas[i]
+        update = -self.lr * grad + self.momentum * self.last_update.get(i, 0)
+        self.last_update[i] = update
+        return update
 
 
 class Adam(Optimizer):
-    """ ADAptive Moment estimation """
+    """Adam (Kingma & Ba): running means of the gradient (`m`) and of its square (`v`), both bias-corrected by the number of
+    updates `t` - which, as in the reference (optim.py:36), counts every PARAMETER's update, not every step."""
     belief = False
 
     def __init__(self, parameters, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                  fused: bool = False, grad_scale: float = 1.0, device_step: bool = False):
         Optimizer.__init__(self, parameters)
-        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
-        self.t = 0
-        self.m = [0] * len(self.parameters)
-        self.v = [0] * len(self.parameters)
+        self.lr, self.eps = lr, eps
+        self.b1, self.b2 = beta1, beta2
+        count = len(self.parameters)
+        self.t, self.m, self.v = 0, [0] * count, [0] * count
         # grad_scale: factor applied to every gradient first (1/world_size in data-parallel training)
         self.fused, self.grad_scale, self.device_step = fused, grad_scale, device_step
         self._step_counter = None
@@ -148,8 +156,8 @@ class Adam(Optimizer):
 
 
 class AdaBelief(Adam):
-    """ Adapting Stepsizes by the Belief in Observed Gradients (arXiv:2010.07468):
-    the second moment tracks (grad - m)^2 instead of grad^2 """
+    """AdaBelief (arXiv:2010.07468): Adam whose second running mean follows (grad - m)^2, the squared surprise, instead
+    of grad^2"""
     belief = True
 
     def second_moment_input(self, grad, m):

@@ -92,3 +92,24 @@ def replay_op_cases(T, golden, check):
                     check(name, "grad%d" % i, t.grad.numpy(), golden[key])
         n += 1
     return n
+
+
+class float64_tape(object):
+    """`with float64_tape():` - CpuTensor builds float64 tensors, so the SAME tape code gives a yardstick in (nearly) exact
+    arithmetic: a float32 result is then judged by its distance to that, not to another float32 result"""
+
+    def __enter__(self):
+        from lightgrad_amd import CpuTensor
+        self._cls, self._saved = CpuTensor, CpuTensor.default_dtype
+        CpuTensor.default_dtype = np.float64
+        return self
+
+    def __exit__(self, *exc):
+        self._cls.default_dtype = self._saved
+        return False
+
+
+def rel_frobenius(got, ref):
+    """||got - ref|| / ||ref|| in float64"""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300))

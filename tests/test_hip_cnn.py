@@ -68,6 +68,7 @@ def test_cnn_training_matches_cpu_backend(hip):
             return self.l1(y.reshape(-1, 5 * 5 * 16))
     np.random.seed(0)
     cpu_model, hip_model = CNN(), CNN()
+    start = [(n, p.numpy().copy()) for n, p in cpu_model.named_parameters()]
     hip_model.load_parameters(cpu_model.named_parameters())
     hip_model.map_parameters(lambda p: p.hip())
     x = np.random.uniform(0, 1, (8, 1, 28, 28)).astype(np.float32)
@@ -83,6 +84,24 @@ def test_cnn_training_matches_cpu_backend(hip):
             opt.step()
             losses.append(l.item())
         out[name] = (losses, [p.numpy() for p in model.parameters()])
-    np.testing.assert_allclose(out["hip"][0], out["cpu"][0], rtol=1e-4)
-    for a, b in zip(out["hip"][1], out["cpu"][1]):
-        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5)
+    # yardstick: the same four steps in float64 (CpuTensor.default_dtype).  AdaBelief divides by the square root of a second
+    # moment that starts near zero, so float32 rounding noise in a gradient is amplified in the first updates: the float32 CPU
+    # backend itself ends 1e-4 .. 1e-3 (relative) from the float64 run - the HIP path must be about as close to it
+    from common import float64_tape, rel_frobenius
+    with float64_tape():
+        ref_model = CNN()
+        ref_model.load_parameters([(n, a.astype(np.float64)) for n, a in start])
+        assert all(p.dtype == np.float64 for p in ref_model.parameters())
+        opt = light.optim.AdaBelief(ref_model.parameters(), lr=1e-3)
+        ref_losses = []
+        for _ in range(4):
+            l = light.loss.mse(ref_model(CpuTensor.from_numpy(x.astype(np.float64))), CpuTensor.from_numpy(t.astype(np.float64)))
+            opt.zero_grad()
+            l.backward()
+            opt.step()
+            ref_losses.append(l.item())
+        ref_params = [p.numpy() for p in ref_model.parameters()]
+    np.testing.assert_allclose(out["hip"][0], ref_losses, rtol=2e-5)
+    for a, b, r in zip(out["hip"][1], out["cpu"][1], ref_params):
+        e_hip, e_cpu = rel_frobenius(a, r), rel_frobenius(b, r)
+        assert e_hip <= max(1e-5, 2 * e_cpu), (e_hip, e_cpu)

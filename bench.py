@@ -387,8 +387,11 @@ def gpu_rank(args, rank, world):
             fence()
             t0 = time.perf_counter()
             for _ in range(reps):
-                (g_multi if unroll > 1 else g_all).replay()
-            opt.on_graph_replay(reps * unroll)
+                if unroll > 1:
+                    g_multi.replay()
+                    opt.on_graph_replay(unroll)
+                else:
+                    step()                          # one replayed step (+ the host-launched exchange and update of the "eager" form)
             fence()
             long_window = {"steps": reps * unroll, "steps_per_sec": round(world * reps * unroll / wall_max(time.perf_counter() - t0), 2)}
 
@@ -640,7 +643,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
     # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (profiles/rN/pmc_traffic.json; separate runs,
     # corrected as MI355X_MICROARCH.md prescribes) - cannot be collected from inside this process
     traffic = None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 traffic = json.load(f).get("sgemm_mfma_256x256_NN_4096", {}).get("hbm_bytes_per_launch")

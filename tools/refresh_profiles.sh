@@ -26,13 +26,15 @@ step timeline 100 "python tools/gemm_timeline.py > $out/gemm_timeline.txt 2>&1";
 # tiny-BERT: one forward+backward kernel by kernel, the variants that were measured against it, its GEMM shapes, its loss kernel
 step berttrace 300 "rocprofv3 --kernel-trace --output-format csv -d $out/berttrace -- python3 tools/bert_bench.py --replays 6 > $out/berttrace.log 2>&1"
 python tools/bert_bench.py --trace $out/berttrace/*/*_kernel_trace.csv > $out/bert_step_trace.txt; tail -30 $out/bert_step_trace.txt
-step bertbench 200 "python tools/bert_bench.py > $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 (weight gradients launched where the tape makes them, dW and dx paired)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 (weight gradients on a second stream: parallel branches of the hipGraph)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 LIGHTGRAD_SIDE_STREAM=1 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1"; cat $out/bert_bench.txt
+step bertbench 200 "python tools/bert_bench.py > $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 (weight gradients launched where the tape makes them, dW and dx paired)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1"; cat $out/bert_bench.txt
 step bertgemm 100 "python tools/bert_gemm_bench.py > $out/bert_gemm_bench.txt 2>&1"; cat $out/bert_gemm_bench.txt
 step cebench 100 "python tools/ce_bench.py > $out/ce_bench.txt 2>&1; LG_CE_HELD=0 python tools/ce_bench.py >> $out/ce_bench.txt 2>&1"; cat $out/ce_bench.txt
 step rehearse 400 "python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-cpu-baseline > $out/bench_rehearsal_two_ranks_one_gpu.json 2> $out/bench_rehearsal.err"; tail -c 300 $out/bench_rehearsal_two_ranks_one_gpu.json
-step dist2 300 "LIGHTGRAD_MULTIPROC_GPU_TESTS=1 python -m pytest tests/test_hip_dist.py -m gpu -q > $out/dist_two_ranks_one_gpu.txt 2>&1"; tail -2 $out/dist_two_ranks_one_gpu.txt
+step dist2 300 "python -m pytest tests/test_hip_dist.py -m gpu -q > $out/dist_two_ranks_one_gpu.txt 2>&1"; tail -2 $out/dist_two_ranks_one_gpu.txt
+step p2pbench 200 "python tools/p2p_bench.py 2 > $out/p2p_bench_cu_masked.txt 2>&1; P2P_BENCH_MASK=0 python tools/p2p_bench.py 2 > $out/p2p_bench_no_mask.txt 2>&1"; cat $out/p2p_bench_cu_masked.txt
+step ipcprobe 100 "tools/ipc_probe.bin > $out/ipc_probe.txt 2>&1"; tail -3 $out/ipc_probe.txt
+step ringlab 100 "tools/gemm_ring_lab.bin > $out/gemm_ring_lab_run.txt 2>&1"; cat $out/gemm_ring_lab_run.txt
 step soak 200 "python tools/soak.py 20 > $out/soak.txt 2>&1"; cat $out/soak.txt
-step branchprobe 100 "python tools/graph_branch_probe.py > $out/graph_branch_probe.txt 2>&1"; cat $out/graph_branch_probe.txt
 # SQ counters of the six MLP GEMM shapes + the head kernels (one counter pair per pass)
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do

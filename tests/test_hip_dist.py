@@ -17,8 +17,8 @@ WORKER = os.path.join("tests", "dist_rank_worker.py")
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def _run(spawn_ranks, tmp_path, *flags, env=None, wait_for_all=False, timeout=300):
-    res = spawn_ranks(2, [WORKER, "--out", str(tmp_path)] + [str(f) for f in flags], env=env, timeout=timeout, wait_for_all=wait_for_all)
+def _run(spawn_ranks, tmp_path, *flags, env=None, wait_for_all=False, timeout=300, world=2):
+    res = spawn_ranks(world, [WORKER, "--out", str(tmp_path)] + [str(f) for f in flags], env=env, timeout=timeout, wait_for_all=wait_for_all)
     assert res["rc"] == 0, "ranks failed (rc %s):\n%s" % (res["rc"], "\n---- next rank ----\n".join(res["outputs"]))
     return res
 
@@ -108,9 +108,31 @@ def test_exchange_at_mnist_mlp_size_in_a_replayed_graph(spawn_ranks, tmp_path):
         np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * scale, err_msg=n)
 
 
-def test_peer_window_collectives(spawn_ranks, tmp_path):
-    res = _run(spawn_ranks, tmp_path, "--mode", "collectives")
-    assert all("collectives ok" in o for o in res["outputs"]), res["outputs"]
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_window_collectives(spawn_ranks, tmp_path, world):
+    res = _run(spawn_ranks, tmp_path, "--mode", "collectives", world=world)
+    assert len(res["outputs"]) == world and all("collectives ok" in o for o in res["outputs"]), res["outputs"]
+
+
+def test_four_ranks_on_one_device(spawn_ranks, tmp_path):
+    """world_size 4 (each rank on a quarter of the CUs): every chunk now has THREE pushers and the owner sums four contributions in
+    rank order; exchange inside the optimizer launch, steps 2.. replayed from a hipGraph.  SUM == gradient of the concatenated
+    four batches, the update uses SUM / 4, four bit-identical replicas."""
+    import np_oracle as O
+    _run(spawn_ranks, tmp_path, "--comm", "p2p", "--fused", 1, "--graph", 1, "--steps", 6, world=4)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(4)]
+    for other in r[1:]:
+        for k in r[0].files:
+            if k.startswith(("w0/", "g/", "w1/", "wf/")):
+                np.testing.assert_array_equal(r[0][k], other[k], err_msg=k)
+    w0 = {n: r[0]["w0/" + n] for n in O.PARAM_ORDER}
+    _, g_cat, _ = O.mlp_loss_and_grads(w0, np.concatenate([q["x"] for q in r]), np.concatenate([q["onehot"] for q in r]))
+    opt = O.AdamState(1e-3, belief=True, eps=0.05)
+    for n in O.PARAM_ORDER:
+        np.testing.assert_allclose(r[0]["g/" + n], g_cat[n], rtol=1e-5, atol=1e-6, err_msg=n)
+        got = r[0]["w1/" + n].astype(np.float64) - w0[n]
+        np.testing.assert_allclose(got, opt.delta(n, g_cat[n] * np.float32(0.25)), rtol=2e-3, atol=1e-8, err_msg=n)
+    assert len({float(q["losses"][0]) for q in r}) == 4               # four different batches
 
 
 def test_a_lost_peer_is_an_error_not_a_hang(spawn_ranks, tmp_path):

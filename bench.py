@@ -70,9 +70,10 @@ def parse():
                          "memory (RCCL refuses a second rank on a device, hipIpc handles are per process) - the multi-rank code of this "
                          "script, of DataParallel and of csrc/p2p.hip runs for real, but N ranks sharing one GPU measure no scaling; "
                          "the metric name says so")
-    ap.add_argument("--graph-steps", type=int, default=8,
+    ap.add_argument("--graph-steps", type=int, default=32,
                     help="training steps recorded per hipGraph (each one complete: forward, backward, exchange, update); a replay "
-                         "boundary costs ~8 us of idle GPU, so several steps per graph amortise it.  1 = one step per replay")
+                         "boundary costs ~8 us of idle GPU, so several steps per graph amortise it (8: 16.74 k, 32: 16.79 k, 50: 16.85 k "
+                         "steps/s; 8 at most with rocprofv3 attached, whose queue interceptor faults on large graphs).  1 = one step per replay")
     ap.add_argument("--dry-run", action="store_true", help="CPU stand-in for the GPU work (launcher / protocol test)")
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds before the self-launcher gives up")
     return ap.parse_args()
@@ -327,7 +328,7 @@ def gpu_rank(args, rank, world):
                 # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
                 # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
                 # on the resident batch; the timed loop below still performs exactly --steps of them.
-                unroll = max(1, min(args.graph_steps, n_steps))
+                unroll = max(1, min(args.graph_steps if not under_profiler else min(args.graph_steps, 8), n_steps))
                 while n_steps % unroll:
                     unroll -= 1
                 if unroll > 1:
@@ -542,7 +543,7 @@ def gpu_rank(args, rank, world):
         # the peer-window form first (the cheapest exchange); the forked RCCL branch does not exist for ranks that share a GPU
         for mode in (["p2p"] if peer is not None else []) + ["graph-inline"] + (["graph"] if comm is not peer else []):
             try:
-                quick_steps = 5 * args.graph_steps
+                quick_steps = 5 * min(args.graph_steps, 8)
                 if os.environ.get("LG_BENCH_SIMULATE_HANG") == mode:          # tests of the watchdog only
                     guarded(mode, "calibration", lambda: time.sleep(10 ** 6))
                 rate = guarded(mode, "calibration", lambda: mlp_leg(mode, n_steps=quick_steps, n_warmup=min(args.warmup, 10), quick=True)["steps_per_s"])

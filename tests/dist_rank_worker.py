@@ -139,6 +139,17 @@ def collectives(args, rank, world):
             t = HipTensor.from_numpy(parts[rank], requires_grad=False)
             comm.broadcast_(t, root)
             np.testing.assert_array_equal(t.numpy(), parts[root], err_msg="broadcast n=%d root=%d" % (n, root))
+    # several 1024-float pieces per workgroup: a launch never has more than 448 workgroups (LIGHTGRAD_TEST_WINDOW_FLOATS >= 2 Mi)
+    big = int(os.environ.get("LIGHTGRAD_TEST_WINDOW_FLOATS", 1 << 16))
+    if big >= (1 << 21):
+        for n in (1 << 20, (1 << 21) - 3):                     # 1024 / 2048 pieces -> 3 / 5 per workgroup, the second with a tail
+            parts = [g.uniform(-1, 1, n).astype(np.float32) for g in rngs]
+            want = parts[0].copy()
+            for q in parts[1:]:
+                want = want + q
+            t = HipTensor.from_numpy(parts[rank], requires_grad=False)
+            comm.allreduce_sum_(t)
+            np.testing.assert_array_equal(t.numpy(), want, err_msg="sum n=%d (multi-piece)" % n)
     # an unaligned view of a bucket (element offset 1): the dword path
     base = np.zeros(4099, np.float32)
     base[1:] = rngs[0].uniform(-1, 1, 4098).astype(np.float32) * (rank + 1)

@@ -108,9 +108,29 @@ def test_exchange_at_mnist_mlp_size_in_a_replayed_graph(spawn_ranks, tmp_path):
         np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * scale, err_msg=n)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_peer_window_collectives(spawn_ranks, tmp_path, world):
-    res = _run(spawn_ranks, tmp_path, "--mode", "collectives", world=world)
+def test_exchange_of_a_bucket_beyond_448_chunks(spawn_ranks, tmp_path):
+    """a 1.06 M-parameter model (1040 chunks of 1024 floats: three pieces per exchange workgroup, parameters that straddle pieces),
+    exchange inside the optimizer launch, replayed from a hipGraph"""
+    import np_oracle as O
+    _run(spawn_ranks, tmp_path, "--comm", "p2p", "--fused", 1, "--graph", 1, "--steps", 4, "--dims", "1000,1050,10", "--batch", 16,
+         env={"LIGHTGRAD_TEST_WINDOW_FLOATS": 1 << 21})
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        if k.startswith(("w0/", "g/", "w1/", "wf/")):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    w0 = {n: r0["w0/" + n] for n in O.PARAM_ORDER}
+    _, g_cat, _ = O.mlp_loss_and_grads(w0, np.concatenate([r0["x"], r1["x"]]), np.concatenate([r0["onehot"], r1["onehot"]]))
+    for n in O.PARAM_ORDER:
+        np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * np.abs(g_cat[n]).max(), err_msg=n)
+    opt = O.AdamState(1e-3, belief=True, eps=0.05)
+    for n in O.PARAM_ORDER:
+        got = r0["w1/" + n].astype(np.float64) - w0[n]
+        np.testing.assert_allclose(got, opt.delta(n, g_cat[n] * np.float32(0.5)), rtol=5e-3, atol=1e-8, err_msg=n)
+
+
+@pytest.mark.parametrize("world,window", [(2, 1 << 16), (4, 1 << 16), (2, 1 << 21)], ids=["two_ranks", "four_ranks", "two_ranks_several_pieces_per_workgroup"])
+def test_peer_window_collectives(spawn_ranks, tmp_path, world, window):
+    res = _run(spawn_ranks, tmp_path, "--mode", "collectives", world=world, env={"LIGHTGRAD_TEST_WINDOW_FLOATS": window})
     assert len(res["outputs"]) == world and all("collectives ok" in o for o in res["outputs"]), res["outputs"]
 
 

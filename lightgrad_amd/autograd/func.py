@@ -28,10 +28,6 @@ class _FunctionType(type):
             Gradients.enable()
 
     def __call__(cls, *args, **kwargs):
-        # tensors passed by keyword are not parents and therefore must not need gradients
-        for v in kwargs.values():
-            assert not (isinstance(v, AbstractTensor) and v.requires_grad), \
-                "Tensors that require gradients must be passed positionally!"
         f = object.__new__(cls)
         f.__init__(*args)
         # one backend per call
@@ -40,13 +36,16 @@ class _FunctionType(type):
             if isinstance(t, AbstractTensor):
                 if tensor_type is None:
                     tensor_type = t.__class__
-                else:
+                elif t.__class__ is not tensor_type:
                     assert isinstance(t, tensor_type), \
                         "All Tensors must be of the same type! %s" % str(
                             tuple(x.__class__.__name__ for x in args if isinstance(x, AbstractTensor)))
-        for t in kwargs.values():
-            if isinstance(t, AbstractTensor) and tensor_type is not None:
-                assert isinstance(t, tensor_type), "All Tensors must be of the same type!"
+        if kwargs:
+            for v in kwargs.values():
+                if isinstance(v, AbstractTensor):
+                    # tensors passed by keyword are not parents and therefore must not need gradients
+                    assert not v.requires_grad, "Tensors that require gradients must be passed positionally!"
+                    assert tensor_type is None or isinstance(v, tensor_type), "All Tensors must be of the same type!"
         if Profiler._active_profilers:
             with Tracker(cls.__name__):
                 out = cls._apply(f, args, kwargs)
@@ -69,11 +68,16 @@ class Function(object, metaclass=_FunctionType):
     def __init__(self, *parents):
         self._parents = parents
         self._saved = ()
+        self._wanting = None
 
     @property
     def parent_tensors(self):
-        """Positional parents that are tensors requiring gradients."""
-        return [t for t in self._parents if isinstance(t, AbstractTensor) and t.requires_grad]
+        """Positional parents that are tensors requiring gradients (settled when the node is made: asked for several times per
+        node by the call protocol and by the backward walk)."""
+        wanting = self._wanting
+        if wanting is None:
+            wanting = self._wanting = [t for t in self._parents if isinstance(t, AbstractTensor) and t._requires_grad]
+        return wanting
 
     def _backpropagate(self, out_grad):
         if Profiler._active_profilers:

@@ -1357,7 +1357,7 @@ def head_mse_forward(y, y_hat):
     out, err, row_loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty((rows,), requires_grad=False)
     _l.check(_l.lib().lg_head_fwd_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
                                       out.ptr, err.ptr, row_loss.ptr, rows, hidden, outs))
-    y._data, y._offset, y._lazy_source = out._data, out._offset, None           # y is real now
+    y._data, y._offset, y._byte_offset, y._lazy_source = out._data, out._offset, out._byte_offset, None           # y is real now
     # the scalar loss stays lazy: the backward launch of this head finishes it (a cross-workgroup sum inside the forward
     # launch would cost 4 us); whoever reads it before that pays one small launch
     loss = HipTensor(None, (), None, 0, _F32)
@@ -1396,7 +1396,7 @@ def _head_backward(x, src, relu, weight, bias, g2):
         db.ptr if db is not None else None, 1 if (acc_b is not None and not bias._consume_zero_pending()) else 0,
         rows, hidden, outs, row_loss.ptr if row_loss is not None else None, loss_out.ptr if loss_out is not None else None))
     if loss_out is not None:
-        loss._data, loss._offset, loss._lazy_source = loss_out._data, loss_out._offset, None
+        loss._data, loss._offset, loss._byte_offset, loss._lazy_source = loss_out._data, loss_out._offset, loss_out._byte_offset, None
         g2._unfinished_loss = None
     if acc_w is not None:
         weight._notify_grad_written()

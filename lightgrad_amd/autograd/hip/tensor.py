@@ -200,18 +200,21 @@ class HipTensor(AbstractTensor):
 
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):
-        assert isinstance(buffer, HipBuffer) or buffer is None        # None: a lazy tensor, see _lazy_source
-        AbstractTensor.__init__(self, data=buffer, requires_grad=requires_grad)
+        assert buffer is None or buffer.__class__ is HipBuffer        # None: a lazy tensor, see _lazy_source
+        # (AbstractTensor.__init__ inlined: this constructor runs ~17 times per eager MLP step)
+        self._data, self._grad, self._grad_shared, self._requires_grad, self._ctx = buffer, None, False, requires_grad, None
         self._dtype = dtype if dtype.__class__ is np.dtype else np.dtype(dtype)
-        self._shape = tuple(map(int, shape))
+        if shape.__class__ is not tuple or (shape and shape[0].__class__ is not int):
+            shape = tuple(map(int, shape))      # lists, numpy integers
+        self._shape = shape
         if strides is None:
-            self._strides, self._dense = contiguous_strides(self._shape), True
+            self._strides, self._dense = contiguous_strides(shape), True
         else:
             self._strides, self._dense = tuple(map(int, strides)), None      # None: not looked at yet (is_contiguous)
-        self._offset = int(offset)
-        assert len(self._shape) == len(self._strides), \
-            "Shapes and strides do not align! (%s <-> %s)" % (self._shape, self._strides)
-        assert len(self._shape) <= 8, "HipTensor supports at most 8 dimensions"
+            assert len(shape) == len(self._strides), "Shapes and strides do not align! (%s <-> %s)" % (shape, self._strides)
+        self._offset = offset if offset.__class__ is int else int(offset)
+        self._byte_offset = self._offset * self._dtype.itemsize
+        assert len(shape) <= 8, "HipTensor supports at most 8 dimensions"
 
     @property
     def dtype(self):
@@ -283,7 +286,7 @@ class HipTensor(AbstractTensor):
                 out = _ops._gemm_fused(x, _ops._swap_last(weight), bias=bias, relu_a=True)[0]
             else:
                 out = _ops._gemm(x, _ops._swap_last(weight), bias=bias)
-        self._data, self._offset, self._lazy_source = out._data, out._offset, None
+        self._data, self._offset, self._byte_offset, self._lazy_source = out._data, out._offset, out._byte_offset, None
 
     def _watch_sources(self, *sources) -> None:
         """register this lazy tensor with the storage of everything it will read (see flush_lazy_readers)"""
@@ -302,7 +305,10 @@ class HipTensor(AbstractTensor):
     @property
     def ptr(self) -> int:
         """device address of element [0, ..., 0]"""
-        return self.data.ptr + self._offset * self._dtype.itemsize
+        buf = self._data
+        if buf is None:
+            buf = self.data                  # a lazy tensor: computed now
+        return buf.ptr + self._byte_offset
 
     def numel(self) -> int:
         n = 1

@@ -442,7 +442,7 @@ class DataParallel(object):
             with Gradients.no_grad():
                 for p, v in zip(self.parameters, pviews):
                     v[...] = p
-                    p._data, p._offset, p._strides, p._dense = v._data, v._offset, v._strides, v._dense      # ... except here
+                    p._data, p._offset, p._byte_offset, p._strides, p._dense = v._data, v._offset, v._byte_offset, v._strides, v._dense      # ... except here
         if broadcast_parameters and comm.world_size > 1:
             self.broadcast_parameters()
         if self.overlap:

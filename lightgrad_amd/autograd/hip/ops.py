@@ -724,8 +724,21 @@ def _is_advanced(i):
 
 
 class _TakePlan(object):
-    """integer-array indexing split into a basic view + ONE gather along an axis of that view (csrc/index.hip)"""
-    __slots__ = ("basic", "axis", "index", "pair")
+    """integer-array indexing split into a basic view + ONE gather along an axis of that view (csrc/index.hip).  `merge` > 1:
+    the gather runs along that many neighbouring axes of the (dense) view taken as one axis, with row-major flat indices"""
+    __slots__ = ("basic", "axis", "index", "pair", "merge")
+
+
+def _host_index(x):
+    """an index array on the host (device-resident ones are read back: their VALUES decide shapes or flat positions here)"""
+    if isinstance(x, HipTensor):
+        return x.numpy()
+    return np.asarray(list(x)) if isinstance(x, range) else np.asarray(x)
+
+
+def _is_bool_index(i):
+    return (isinstance(i, HipTensor) and i._dtype == np.dtype(np.bool_)) or (isinstance(i, np.ndarray) and i.dtype == np.bool_ and i.ndim > 0) \
+        or (isinstance(i, list) and len(i) > 0 and isinstance(i[0], (bool, np.bool_)))
 
 
 def _index_tensor(x, axis_len):
@@ -761,10 +774,30 @@ def _take_plan(a, idx):
     adv = [k for k, i in enumerate(idx) if _is_advanced(i)]
     if not adv:
         return None
-    if len(adv) > 2 or (len(adv) == 2 and adv[1] != adv[0] + 1):
-        raise NotImplementedError("HipTensor indexing supports one integer-array index, or the pair `range(n), labels` on "
-                                  "neighbouring axes; got %d array indices" % len(adv))
+    if any(_is_bool_index(idx[k]) for k in adv):
+        # a boolean mask selects where it is True: numpy's x[mask] == x[mask.nonzero()] - one index array per axis the mask spans
+        # (cpu/ops.py:234-255 hands the mask to numpy).  The result's SIZE depends on the mask's values: read it back.
+        expanded = []
+        for i in idx:
+            if _is_advanced(i) and _is_bool_index(i):
+                expanded.extend(np.nonzero(_host_index(i).astype(np.bool_)) + (_MaskShape(_host_index(i).shape),))
+            else:
+                expanded.append(i)
+        idx, masks = [], []
+        for i in expanded:
+            if isinstance(i, _MaskShape):
+                masks.append((len(idx) - len(i.shape), i.shape))          # position of the mask's first index array, its shape
+            else:
+                idx.append(i)
+        idx = tuple(idx)
+        adv = [k for k, i in enumerate(idx) if _is_advanced(i)]
+    else:
+        masks = []
+    if len(adv) > 1 and adv[-1] - adv[0] != len(adv) - 1:
+        raise NotImplementedError("HipTensor indexing: index arrays must sit on neighbouring axes (numpy moves the result dimensions "
+                                  "of separated index arrays to the front; not built)")
     plan = _TakePlan()
+    plan.merge = 1
     plan.basic = tuple(slice(None) if _is_advanced(i) else i for i in idx)
     # axis of the basic VIEW the first array index applies to: entries in front of it that produce a dimension
     n_real = _py.sum(1 for i in idx if i is not None and i is not Ellipsis)
@@ -776,25 +809,62 @@ def _take_plan(a, idx):
             axis += 1
     plan.axis = axis
     view_shape = _idx_view(a, plan.basic)._shape
+    for pos, mshape in masks:
+        ax0 = axis + (pos - adv[0])
+        if tuple(view_shape[ax0:ax0 + len(mshape)]) != tuple(mshape):
+            raise IndexError("boolean index did not match indexed array: mask of shape %s on dimensions of shape %s"
+                             % (mshape, tuple(view_shape[ax0:ax0 + len(mshape)])))
     if len(adv) == 1:
         plan.pair = False
         plan.index = _index_tensor(idx[adv[0]], view_shape[axis])
-    else:
+    elif len(adv) == 2 and _is_arange(idx[adv[0]], view_shape[axis]) and not masks:
         n = view_shape[axis]
-        if not _is_arange(idx[adv[0]], n):
-            raise NotImplementedError("of two array indices the first must be range(n) over its whole axis (the `y[range(n), labels]` "
-                                      "form of loss.cross_entropy)")
         plan.pair = True
         plan.index = _index_tensor(idx[adv[1]], view_shape[axis + 1])
         if plan.index._shape != (n,):
             raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes (%d,) %s" % (n, plan.index._shape))
+    else:
+        # several index arrays on neighbouring axes: broadcast together, validated and folded into ONE row-major flat index over
+        # those axes on the host (a device-resident index array is read back for it); the kernels then gather / scatter along the
+        # merged axis of the dense view
+        k = len(adv)
+        dims = tuple(view_shape[axis:axis + k])
+        arrays = []
+        for j, pos in enumerate(adv):
+            arr = _host_index(idx[pos])
+            if arr.dtype.kind not in "iu":
+                raise IndexError("arrays used as indices must be of integer (or boolean) type (got %s)" % arr.dtype)
+            arr = arr.astype(np.int64)
+            if arr.size and (arr.min() < -dims[j] or arr.max() >= dims[j]):
+                bad = arr[(arr < -dims[j]) | (arr >= dims[j])].flat[0]
+                raise IndexError("index %d is out of bounds for axis with size %d" % (bad, dims[j]))
+            arrays.append(np.where(arr < 0, arr + dims[j], arr))
+        try:
+            arrays = np.broadcast_arrays(*arrays)
+        except ValueError:
+            raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes %s"
+                             % " ".join(str(x.shape) for x in arrays))
+        flat = np.ravel_multi_index(tuple(arrays), dims) if arrays[0].size else np.zeros(arrays[0].shape, np.int64)
+        plan.pair = False
+        plan.merge = k
+        plan.index = HipTensor.from_numpy(np.ascontiguousarray(flat, dtype=np.int64), requires_grad=False)
     return plan
+
+
+class _MaskShape(object):
+    """marker left behind the index arrays a boolean mask was turned into (its shape is checked against the indexed axes)"""
+    __slots__ = ("shape",)
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
 
 
 def _take_extents(view_shape, plan):
     """(outer, axis_len, inner, pair_period, result shape) of a plan applied to a dense tensor of `view_shape`"""
     ax = plan.axis
     prod = lambda dims: int(np.prod(dims, dtype=np.int64)) if len(dims) else 1      # noqa: E731
+    if plan.merge > 1:
+        view_shape = view_shape[:ax] + (prod(view_shape[ax:ax + plan.merge]),) + view_shape[ax + plan.merge:]
     if plan.pair:
         n = view_shape[ax]
         return prod(view_shape[:ax]) * n, view_shape[ax + 1], prod(view_shape[ax + 2:]), n, view_shape[:ax] + (n,) + view_shape[ax + 2:]

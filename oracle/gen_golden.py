@@ -247,6 +247,52 @@ def main():
         fi["dataset/x%d" % k], fi["dataset/y%d" % k] = bx, by
     np.savez_compressed(os.path.join(OUT, "fancy_index.npz"), **fi)
 
+    # ---------------------------------------------------------------- more index forms the reference's CPU path accepts through numpy
+    # (cpu/ops.py:234-255): several index arrays on neighbouring axes (broadcast together), boolean masks.  Unique index tuples:
+    # the reference ASSIGNS in getitem.backward (cpu/ops.py:245), which equals accumulation only without repeats.
+    fi2 = {}
+    rng5 = np.random.RandomState(777)
+
+    def run_multi(name, shape, make_index, arrays):
+        a = f32(rng5, -1, 1, shape)
+        t = T.from_numpy(a.copy())
+        y = t[make_index(lambda v: T.from_numpy(v, requires_grad=False))]
+        w = f32(rng5, -1, 1, y.shape)
+        (y * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        fi2[name + "/in"], fi2[name + "/out"], fi2[name + "/w"], fi2[name + "/grad"] = a, np.array(y.numpy()), w, np.array(t.grad.numpy())
+        for k, v in arrays.items():
+            fi2["%s/%s" % (name, k)] = v
+    flat = rng5.permutation(6 * 5)[:7]
+    r2, c2 = (flat // 5).astype(np.int64), (flat % 5).astype(np.int64)
+    run_multi("two_arrays", (6, 5, 3), lambda D: (D(r2), D(c2)), {"i0": r2, "i1": c2})
+    flat = rng5.permutation(4 * 3 * 5)[:9]
+    a3, b3, c3 = (flat // 15).astype(np.int64), ((flat // 5) % 3).astype(np.int32), (flat % 5).astype(np.int64)
+    run_multi("three_arrays", (4, 3, 5), lambda D: (D(a3), D(b3), D(c3)), {"i0": a3, "i1": b3, "i2": c3})
+    rb, cb = rng5.permutation(6)[:3].reshape(3, 1).astype(np.int64), rng5.permutation(7)[:4].astype(np.int64)
+    run_multi("two_arrays_broadcast", (6, 7), lambda D: (D(rb), D(cb)), {"i0": rb, "i1": cb})
+    rm, cm = rng5.permutation(5)[:4].astype(np.int64), rng5.permutation(6)[:4].astype(np.int64)
+    run_multi("two_arrays_middle", (2, 5, 6, 3), lambda D: (slice(None), D(rm), D(cm)), {"i0": rm, "i1": cm})
+    m1 = rng5.uniform(0, 1, 8) > 0.5
+    m1[0] = True
+    run_multi("mask_axis0", (8, 4), lambda D: D(m1), {"mask": m1})
+    m2 = rng5.uniform(0, 1, (5, 6)) > 0.6
+    m2[2, 3] = True
+    run_multi("mask_full", (5, 6), lambda D: D(m2), {"mask": m2})
+    run_multi("mask_two_axes_of_three", (5, 6, 2), lambda D: D(m2), {"mask": m2})
+    # in-place forms
+    a = f32(rng5, -1, 1, (6, 5, 3))
+    v = f32(rng5, -1, 1, (7, 3))
+    t = T.from_numpy(a.copy(), requires_grad=False)
+    with light.no_grad():
+        t[T.from_numpy(r2, requires_grad=False), T.from_numpy(c2, requires_grad=False)] = T.from_numpy(v, requires_grad=False)
+    fi2["put_two_arrays/in"], fi2["put_two_arrays/i0"], fi2["put_two_arrays/i1"], fi2["put_two_arrays/val"], fi2["put_two_arrays/out"] = a, r2, c2, v, np.array(t.numpy())
+    a = f32(rng5, -1, 1, (5, 6))
+    t = T.from_numpy(a.copy(), requires_grad=False)
+    with light.no_grad():
+        t[T.from_numpy(m2, requires_grad=False)] = 0.25
+    fi2["put_mask_scalar/in"], fi2["put_mask_scalar/mask"], fi2["put_mask_scalar/out"] = a, m2, np.array(t.numpy())
+    np.savez_compressed(os.path.join(OUT, "fancy_index_multi.npz"), **fi2)
+
     # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
     # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
     # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.

@@ -81,3 +81,46 @@ def test_repeated_indices_accumulate_in_backward():
     y = t[np.asarray([1, 1, 3])]
     (y * CpuTensor.from_numpy(np.asarray([[1, 2], [10, 20], [5, 5]], np.float32), requires_grad=False)).backward(allow_fill=True)
     np.testing.assert_array_equal(t.grad.numpy(), [[0, 0], [11, 22], [0, 0], [5, 5]])
+
+
+# ---- several index arrays on neighbouring axes, boolean masks (tests/golden/fancy_index_multi.npz, recorded from the reference) ----
+MULTI_CASES = {
+    "two_arrays": lambda D, g, n: (D(g[n + "/i0"]), D(g[n + "/i1"])),
+    "three_arrays": lambda D, g, n: (D(g[n + "/i0"]), D(g[n + "/i1"]), D(g[n + "/i2"])),
+    "two_arrays_broadcast": lambda D, g, n: (D(g[n + "/i0"]), D(g[n + "/i1"])),
+    "two_arrays_middle": lambda D, g, n: (slice(None), D(g[n + "/i0"]), D(g[n + "/i1"])),
+    "mask_axis0": lambda D, g, n: D(g[n + "/mask"]),
+    "mask_full": lambda D, g, n: D(g[n + "/mask"]),
+    "mask_two_axes_of_three": lambda D, g, n: D(g[n + "/mask"]),
+}
+
+
+def check_multi(cls, g, name):
+    for as_tensor in (True, False):                 # index arrays as backend tensors, and as host arrays
+        D = (lambda v: cls.from_numpy(v, requires_grad=False)) if as_tensor else (lambda v: v)
+        t = cls.from_numpy(g[name + "/in"].copy())
+        y = t[MULTI_CASES[name](D, g, name)]
+        np.testing.assert_array_equal(y.numpy(), g[name + "/out"])
+        (y * cls.from_numpy(g[name + "/w"], requires_grad=False)).backward(allow_fill=True)
+        np.testing.assert_array_equal(t.grad.numpy(), g[name + "/grad"])
+
+
+def check_multi_inplace(cls, g):
+    D = lambda v: cls.from_numpy(v, requires_grad=False)          # noqa: E731
+    t = cls.from_numpy(g["put_two_arrays/in"].copy(), requires_grad=False)
+    with light.no_grad():
+        t[D(g["put_two_arrays/i0"]), D(g["put_two_arrays/i1"])] = D(g["put_two_arrays/val"])
+    np.testing.assert_array_equal(t.numpy(), g["put_two_arrays/out"])
+    t = cls.from_numpy(g["put_mask_scalar/in"].copy(), requires_grad=False)
+    with light.no_grad():
+        t[D(g["put_mask_scalar/mask"])] = 0.25
+    np.testing.assert_array_equal(t.numpy(), g["put_mask_scalar/out"])
+
+
+@pytest.mark.parametrize("name", sorted(MULTI_CASES))
+def test_several_index_arrays_and_masks(name):
+    check_multi(CpuTensor, load_golden("fancy_index_multi.npz"), name)
+
+
+def test_several_index_arrays_and_masks_in_place():
+    check_multi_inplace(CpuTensor, load_golden("fancy_index_multi.npz"))

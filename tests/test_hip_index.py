@@ -7,7 +7,7 @@ import pytest
 import lightgrad_amd as light
 from lightgrad_amd import CpuTensor
 from conftest import load_golden
-from test_fancy_index_cpu import TAKE_CASES, PAIR_CASES, check_take, check_inplace, check_dataset
+from test_fancy_index_cpu import TAKE_CASES, PAIR_CASES, MULTI_CASES, check_take, check_inplace, check_dataset, check_multi, check_multi_inplace
 
 pytestmark = pytest.mark.gpu
 
@@ -26,6 +26,29 @@ def test_pair_rows_labels(hip, name):
 
 def test_inplace_forms(hip):
     check_inplace(hip, load_golden("fancy_index.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(MULTI_CASES))
+def test_several_index_arrays_and_masks(hip, name):
+    """two / three index arrays on neighbouring axes (broadcast together) and boolean masks, as the reference's CPU path takes them
+    through numpy (cpu/ops.py:234-255): values, gradients and in-place forms bit for bit against fixtures recorded from it"""
+    check_multi(hip, load_golden("fancy_index_multi.npz"), name)
+
+
+def test_several_index_arrays_and_masks_in_place(hip):
+    check_multi_inplace(hip, load_golden("fancy_index_multi.npz"))
+
+
+def test_index_forms_that_are_errors(hip):
+    t = hip.from_numpy(np.zeros((4, 5, 6), np.float32))
+    with pytest.raises(IndexError, match="out of bounds"):
+        t[np.asarray([0, 1]), np.asarray([1, 5])]
+    with pytest.raises(IndexError, match="broadcast"):
+        t[np.asarray([0, 1, 2]), np.asarray([1, 2])]
+    with pytest.raises(IndexError, match="boolean index did not match"):
+        t[np.zeros((4, 4), bool)]
+    with pytest.raises(NotImplementedError, match="neighbouring"):
+        t[np.asarray([0, 1]), :, np.asarray([1, 2])]
 
 
 def test_dataset_epoch_matches_reference(hip):
@@ -94,8 +117,7 @@ def test_index_out_of_range_is_reported(hip):
     t = hip.from_numpy(np.arange(12, dtype=np.float32).reshape(4, 3), requires_grad=False)
     with pytest.raises(IndexError):
         t[[0, 4]]                                                                     # host-side index: at once, like numpy
-    with pytest.raises(NotImplementedError):
-        t[[0, 1], [0, 1]]                                                             # general pairs of index arrays: not on the device
+    np.testing.assert_array_equal(t[[0, 1], [0, 1]].numpy(), [0., 4.])                # pairs of index arrays: one flat index, host-built
     bad = hip.from_numpy(np.asarray([1, 7], np.int64), requires_grad=False)
     out = t[bad]                                                                      # device-side index: the kernel cannot raise ...
     with pytest.raises(IndexError):

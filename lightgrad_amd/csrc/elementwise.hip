@@ -259,9 +259,9 @@ __global__ void __launch_bounds__(256) ew_transposed_tile(EwArgs a, IterDesc d, 
 // float4 form of the same tile: R % 4 == 0, C % 4 == 0, every operand 16-byte aligned with leading strides % 4 == 0.
 // Transposed inputs are read as float4 along their fast axis (16 lanes = one 256-byte run, 16 runs per pass) and
 // scattered into tile[r][c]; the compute pass reads 4 consecutive c per lane and moves float4 on the row-major side.
-template <class Op>
+template <class Op, int NT>
 __global__ void __launch_bounds__(256) ew_transposed_tile_v4(EwArgs a, IterDesc d, int tr_mask, int tiles_r, int tiles_c) {
-    __shared__ float tile[2][kTT][kTT + 1];
+    __shared__ float tile[NT][kTT][kTT + 1];
     const int64_t R = d.shape[0], C = d.shape[1];
     int64_t r0, c0;
     diagonal_tile(blockIdx.x, tiles_r, tiles_c, r0, c0);
@@ -323,6 +323,94 @@ __global__ void __launch_bounds__(256) ew_transposed_tile_v4(EwArgs a, IterDesc 
                 *reinterpret_cast<float4*>(a.out[o] + r * d.stride[kOutSlot + o][0] + c) = make_float4(y[o][0], y[o][1], y[o][2], y[o][3]);
         }
     }
+}
+
+// Matrices the Infinity Cache does not hold, ONE transposed input: a 128 x 128 tile moved by 1024 threads, so that every
+// visit to a DRAM page moves 512 bytes on both sides instead of 256 while the CU still holds 32 waves (two workgroups of
+// 66 KiB of LDS from the dynamic pool).  Measured at 8192^2 (`a + b.T` / `contiguous(b.T)` / `a += b.T`, TB/s): 64 x 64 by
+// 256 threads 5.28 / 5.16 / 5.20; this form 5.90 / 5.72 / 5.87; the same tile by 256 threads 4.30 / 4.03 / 4.28 (8 waves
+// per CU); 256 x 128 and 128 x 256 by 1024 threads 5.68 / 5.22 and 5.61 / 5.17; walking 2 x 2 or 4 x 4 groups of 64 x 64
+// tiles together: no change; a lane map without LDS bank conflicts: 5.73 / 5.64 (`profiles/r3/transposed_tiles.txt`).
+template <class Op, int TR, int TC, int NTH>
+__global__ void __launch_bounds__(NTH) ew_transposed_big_v4(EwArgs a, IterDesc d, int ti, int tiles_r, int tiles_c) {
+    extern __shared__ float big_tile[];
+    constexpr int PITCH = TC + 1;
+    constexpr int QR = TR / 4, QC = TC / 4;            // float4 per run on the transposed side / per output row
+    constexpr int RUNS = NTH / QR, ROWS = NTH / QC;    // runs (output rows) one pass of the workgroup covers
+    const int64_t R = d.shape[0], C = d.shape[1];
+    const unsigned b = blockIdx.x;
+    const unsigned tc = b % unsigned(tiles_c), j = b / unsigned(tiles_c);
+    const unsigned tr = (j + tc) % unsigned(tiles_r);
+    const int64_t r0 = int64_t(tr) * TR, c0 = int64_t(tc) * TC;
+    {
+        const int q = threadIdx.x % QR, line = threadIdx.x / QR;
+        const int64_t ld = d.stride[kInSlot + ti][1];
+        const float* src = a.in[ti];
+#pragma unroll
+        for (int p = 0; p < TC / RUNS; ++p) {
+            const int cc = p * RUNS + line;
+            const int64_t r = r0 + 4 * q, c = c0 + cc;
+            if (r < R && c < C) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c * ld + r);
+                big_tile[(4 * q + 0) * PITCH + cc] = v.x;
+                big_tile[(4 * q + 1) * PITCH + cc] = v.y;
+                big_tile[(4 * q + 2) * PITCH + cc] = v.z;
+                big_tile[(4 * q + 3) * PITCH + cc] = v.w;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x % QC, line = threadIdx.x / QC;
+#pragma unroll
+    for (int p = 0; p < TR / ROWS; ++p) {
+        const int rr = p * ROWS + line;
+        const int64_t r = r0 + rr, c = c0 + 4 * q;
+        if (r < R && c < C) {
+            float x[4][4];
+#pragma unroll
+            for (int i = 0; i < Op::NIN; ++i) {
+                if (a.in[i] == nullptr) {
+                    x[i][0] = x[i][1] = x[i][2] = x[i][3] = a.scalar;
+                } else if (i == ti) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[i][k] = big_tile[rr * PITCH + 4 * q + k];
+                } else if (d.stride[kInSlot + i][1] != 0) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.in[i] + r * d.stride[kInSlot + i][0] + c);
+                    x[i][0] = v.x; x[i][1] = v.y; x[i][2] = v.z; x[i][3] = v.w;
+                } else {
+                    const float v = a.in[i][r * d.stride[kInSlot + i][0]];
+                    x[i][0] = x[i][1] = x[i][2] = x[i][3] = v;
+                }
+            }
+            float y[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float in[4], out[2];
+#pragma unroll
+                for (int i = 0; i < Op::NIN; ++i) in[i] = x[i][k];
+                Op::apply(in, out);
+#pragma unroll
+                for (int o = 0; o < Op::NOUT; ++o) y[o][k] = out[o];
+            }
+#pragma unroll
+            for (int o = 0; o < Op::NOUT; ++o)
+                *reinterpret_cast<float4*>(a.out[o] + r * d.stride[kOutSlot + o][0] + c) = make_float4(y[o][0], y[o][1], y[o][2], y[o][3]);
+        }
+    }
+}
+
+template <class Op, int TR, int TC, int NTH>
+static void launch_transposed_big(hipStream_t s, const EwArgs& args, const IterDesc& d, int ti) {
+    constexpr size_t lds = size_t(TR) * (TC + 1) * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ew_transposed_big_v4<Op, TR, TC, NTH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        once = true;
+    }
+    const int64_t tiles_r = (d.shape[0] + TR - 1) / TR, tiles_c = (d.shape[1] + TC - 1) / TC;
+    hipLaunchKernelGGL((ew_transposed_big_v4<Op, TR, TC, NTH>), dim3(unsigned(tiles_r * tiles_c)), dim3(NTH), lds, s, args, d, ti,
+                       int(tiles_r), int(tiles_c));
 }
 
 // ---- dense 2-D outputs, any 2-D inputs ---------------------------------------------------
@@ -458,8 +546,14 @@ static int launch_ew(const EwArgs& args, const IterDesc& d) {
                     if ((tr_mask >> i) & 1) v4 = aligned16(args.in[i]) && s1 % 4 == 0;
                     else if (s1 == 1) v4 = aligned16(args.in[i]) && s0 % 4 == 0;
                 }
-                if (v4)
-                    hipLaunchKernelGGL((ew_transposed_tile_v4<Op>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
+                const bool one = __builtin_popcount(tr_mask) == 1;
+                if (v4 && one && d.numel >= (int64_t(1) << 25))                   // 128 MiB and more per operand
+                    launch_transposed_big<Op, 128, 128, 1024>(s, args, d, __builtin_ctz(tr_mask));
+                else if (v4 && one)
+                    hipLaunchKernelGGL((ew_transposed_tile_v4<Op, 1>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
+                                       tr_mask, int(tiles_r), int(tiles_c));
+                else if (v4)
+                    hipLaunchKernelGGL((ew_transposed_tile_v4<Op, 2>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,
                                        tr_mask, int(tiles_r), int(tiles_c));
                 else
                     hipLaunchKernelGGL((ew_transposed_tile<Op>), dim3(unsigned(tiles_r * tiles_c)), dim3(256), 0, s, args, d,

@@ -159,8 +159,9 @@ def test_views_and_indexing(hip):
     b[:, 2, :] = a[0, 0]
     np.testing.assert_array_equal(t.numpy(), b)
     np.testing.assert_array_equal(t[[0, 1]].numpy(), b[[0, 1]])      # integer-array index: device gather (tests/test_hip_index.py)
+    np.testing.assert_array_equal(t[[0, 1], [1, 2], [0, 0]].numpy(), b[[0, 1], [1, 2], [0, 0]])   # three index arrays: one flat index
     with pytest.raises(NotImplementedError):
-        t[[0, 1], [1, 2], [0, 0]]                                  # three index arrays: not on the device
+        t[[0, 1], :, [0, 0]]                                       # index arrays on axes that are not neighbours
     with pytest.raises(IndexError):
         t[6]
 
@@ -275,6 +276,28 @@ def test_transposed_operand_tiles(hip, shape):
     if r > 20 and c > 20:                                           # offset views: no operand is 16-byte aligned any more
         np.testing.assert_array_equal((ta[1:, 1:] + tbt.transpose(1, 0)[1:, 1:]).numpy(), a[1:, 1:] + bt.T[1:, 1:])
         np.testing.assert_array_equal((ta[:-4, 4:] + tbt[4:, :-4].transpose(1, 0)).numpy(), a[:-4, 4:] + bt[4:, :-4].T)
+
+
+@pytest.mark.parametrize("shape", [(5796, 5804), (8192, 4096), (4100, 8200)])
+def test_transposed_operand_large_tiles(hip, shape):
+    """from 2^25 elements on, one transposed input goes through 128 x 128 tiles moved by 1024 threads: whole tiles and
+    ragged edges (extents that are multiples of 4 but not of 128), next to a dense and a column operand, in place, and the
+    gradient of a transposed view; exact"""
+    rng = np.random.RandomState(5)
+    r, c = shape
+    assert r * c >= 1 << 25
+    a = rng.uniform(-1, 1, (r, c)).astype(np.float32)
+    bt = rng.uniform(-1, 1, (c, r)).astype(np.float32)
+    col = rng.uniform(-1, 1, (r, 1)).astype(np.float32)
+    ta, tbt, tcol = hip.from_numpy(a), hip.from_numpy(bt), hip.from_numpy(col)
+    np.testing.assert_array_equal(tbt.transpose(1, 0).contiguous().numpy(), bt.T)
+    np.testing.assert_array_equal((ta + tbt.transpose(1, 0)).numpy(), a + bt.T)
+    np.testing.assert_array_equal((tbt.transpose(1, 0) * tcol).numpy(), bt.T * col)
+    with light.no_grad():
+        ta += tbt.transpose(1, 0)
+    np.testing.assert_array_equal(ta.numpy(), a + bt.T)
+    (tbt.transpose(1, 0) * ta).backward(allow_fill=True)                       # two outputs from (b^T, a, ones)
+    np.testing.assert_array_equal(tbt.grad.numpy(), (a + bt.T).T)
 
 
 @pytest.mark.parametrize("shape", [(1024, 30522), (36, 10), (4, 7), (128, 513), (2, 3, 5, 26)])

@@ -36,6 +36,7 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="run the cases whose name contains this text")
     args = ap.parse_args()
     L.lib()
     print("%-34s %-16s %10s %10s %8s" % ("kernel", "shape", "ms", "GB/s", "of 8TB/s"))
@@ -77,6 +78,8 @@ def main():
             ("fill", 4 * n, lambda: out.fill(0.0)),
         ]
         for name, nbytes, fn in cases:
+            if args.only not in name:
+                continue
             ms = timed(fn, args.iters)
             gbs = nbytes / ms / 1e6
             shp = "%dx%d" % (sq if ".T" in name else shape)

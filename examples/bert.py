@@ -76,10 +76,15 @@ class BertSelfAttention(nn.Module):
 
     def forward(self, hidden, attention_mask=None):
         b, s, _ = hidden.shape
+        q, k, v = self.query(hidden), self.key(hidden), self.value(hidden)
+        if attention_mask is None and hasattr(q, "attention") and q.attention_supported(self.h):
+            # the backend's one-launch form of everything below (scores, scaling, softmax, context), forward and backward
+            context = q.attention(k, v, heads=self.h, scale=math.sqrt(self.d) ** -1)
+            return context, context.attention_probs
         # head split: (b, s, h*d) -> (b, h, s, d) as stride permutations, no copies
-        q = self.query(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
-        k = self.key(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 3, 1)
-        v = self.value(hidden).reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
+        q = q.reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
+        k = k.reshape(b, s, self.h, self.d).transpose(0, 2, 3, 1)
+        v = v.reshape(b, s, self.h, self.d).transpose(0, 2, 1, 3)
         scores = q @ k
         if attention_mask is None and hasattr(scores, "scaled_softmax"):
             # the backend's one-kernel form of the two lines below: the same x * sqrt(d)**-1, rounded to fp32, then softmax

@@ -303,6 +303,27 @@ int lg_put_axis(int itemsize, void* dst, int64_t outer, int64_t axis_len, int64_
 int lg_scatter_add_axis_f32(float* dst, int64_t outer, int64_t axis_len, int64_t inner,
                             const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const float* src);
 
+/* ---- self-attention of a short sequence, one launch each way (csrc/attention.hip) ------------------------
+ * Per (batch, head): P = softmax((Q K^T) * scale), O = P V (reference examples/bert.py:78-88: scores GEMM, `/ sqrt(d)`,
+ * softmax, context GEMM - four kernels through kernels.dot / kernels.atom / the softmax composite), and its backward
+ * dV = P^T dO, dS = P o (dO V^T - shift) * scale, dQ = dS K, dK = dS^T Q (dot.backward twice and the softmax composite's
+ * backward).  Q, K, V, O, dO, dQ, dK, dV are addressed as (batch, position, head, d): element at X + b * sbX + pos * ldX +
+ * head * D + d - the (b, s, heads * D) output of a Linear as it stands, no head-split copies; P is a dense
+ * (batch, heads, S, S) tensor, written by the forward (the model returns it) and read by the backward.
+ * Supported: D = 32 or 64, S = 32, 64, 96 or 128 (lg_attention_supported); operands 16-byte aligned, pitches multiples of 4.
+ * The scaled scores are rounded to fp32 before the softmax and the backward's row shift is formed in double, like the separate
+ * kernels (lg_softmax_scaled_f32 / _bwd_f32); sums run in a different order than the GEMM kernels', so values agree with the
+ * composite form to rounding, not bit for bit. */
+int lg_attention_supported(int64_t S, int64_t D);
+int lg_attention_fwd_f32(const float* q, int64_t ldq, int64_t sbq, const float* k, int64_t ldk, int64_t sbk,
+                         const float* v, int64_t ldv, int64_t sbv, float* o, int64_t ldo, int64_t sbo, float* p,
+                         int64_t batch, int64_t heads, int64_t S, int64_t D, float scale);
+int lg_attention_bwd_f32(const float* q, int64_t ldq, int64_t sbq, const float* k, int64_t ldk, int64_t sbk,
+                         const float* v, int64_t ldv, int64_t sbv, const float* g, int64_t ldg, int64_t sbg,
+                         const float* p, float* dq, int64_t lddq, int64_t sbdq, float* dk, int64_t lddk, int64_t sbdk,
+                         float* dv, int64_t lddv, int64_t sbdv, int64_t batch, int64_t heads, int64_t S, int64_t D,
+                         float scale);
+
 /* ---- two independent products in one launch ----------------------------------------------------------
  * lg_gemm_pair_begin(); <product 1>; <product 2>; lg_gemm_pair_end();   with products issued through
  * lg_gemm_f32 / lg_gemm_rowsum_f32 / lg_gemm_fused_f32.  If the first resolves to the 64x64 tile with an

@@ -99,6 +99,9 @@ PROTOTYPES = {
     "lg_softmax_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_softmax_scaled_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float]),
     "lg_softmax_scaled_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float]),
+    "lg_attention_supported": (c_int, [c_int64, c_int64]),
+    "lg_attention_fwd_f32": (c_int, [c_void_p, c_int64, c_int64] * 4 + [c_void_p] + [c_int64] * 4 + [c_float]),
+    "lg_attention_bwd_f32": (c_int, [c_void_p, c_int64, c_int64] * 4 + [c_void_p] + [c_void_p, c_int64, c_int64] * 3 + [c_int64] * 4 + [c_float]),
     "lg_layernorm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_double]),
     "lg_layernorm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64]),
     "lg_cross_entropy_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64]),

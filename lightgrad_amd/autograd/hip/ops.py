@@ -1537,6 +1537,57 @@ def _scaled_softmax(t, scale, axis=-1):
 HipTensor.scaled_softmax = _scaled_softmax
 
 
+def _token_rows(t):
+    """(tensor, row pitch, batch pitch) of a (batch, positions, width) tensor whose rows the attention kernels can address as
+    they lie: width contiguous, pitches multiples of 4, 16-byte aligned; anything else is copied once"""
+    st, sh = t._strides, t._shape
+    if st[2] != 1 or st[1] % 4 or st[0] % 4 or st[1] < sh[2] or t._byte_offset % 16:
+        t = t.contiguous()
+        st = t._strides
+    return t, st[1], st[0]
+
+
+def attention_supported(q, heads):
+    """does `q.attention(k, v, heads, scale)` exist for this shape? (b, s, heads * d) with d = 32 or 64 and s = 32 .. 128 in 32s"""
+    return len(q._shape) == 3 and q._dtype == _F32 and q._shape[2] % heads == 0 and \
+        bool(_l.lib().lg_attention_supported(q._shape[1], q._shape[2] // heads))
+
+
+@HipTensor.register_op()
+class attention(Function):
+    """ softmax((q k^T) * scale) v per head, forward and backward in one launch each (csrc/attention.hip); q, k, v are the
+    (batch, positions, heads * d) outputs of the three projections as they stand - the head split of examples/bert.py:78-80
+    happens in the kernels' addressing.  The probabilities (batch, heads, s, s) the reference model returns next to the context
+    (bert.py:88) are on the result as `.attention_probs`, outside the tape (the composite form differentiates through them) """
+    def forward(ctx, q, k, v, heads=1, scale=1.0):
+        _require_f32(q, k, v)
+        assert q._shape == k._shape == v._shape and attention_supported(q, heads), \
+            "attention: unsupported shapes %s / %s / %s with %d heads" % (q._shape, k._shape, v._shape, heads)
+        b, s, width = q._shape
+        d = width // heads
+        (q, ldq, sbq), (k, ldk, sbk), (v, ldv, sbv) = _token_rows(q), _token_rows(k), _token_rows(v)
+        out = HipTensor.empty((b, s, width))
+        probs = HipTensor.empty((b, heads, s, s), requires_grad=False)
+        _l.check(_l.lib().lg_attention_fwd_f32(q.ptr, ldq, sbq, k.ptr, ldk, sbk, v.ptr, ldv, sbv, out.ptr, width, s * width,
+                                               probs.ptr, b, heads, s, d, float(scale)))
+        ctx.save_for_backward(q, k, v, probs, heads, float(scale))
+        out.attention_probs = probs
+        return out
+
+    def backward(ctx, out_grad):
+        q, k, v, probs, heads, scale = ctx.get_saved_tensors()
+        b, s, width = q._shape
+        (q, ldq, sbq), (k, ldk, sbk), (v, ldv, sbv), (g, ldg, sbg) = _token_rows(q), _token_rows(k), _token_rows(v), _token_rows(out_grad)
+        dq, dk, dv = HipTensor.empty((b, s, width)), HipTensor.empty((b, s, width)), HipTensor.empty((b, s, width))
+        _l.check(_l.lib().lg_attention_bwd_f32(q.ptr, ldq, sbq, k.ptr, ldk, sbk, v.ptr, ldv, sbv, g.ptr, ldg, sbg, probs.ptr,
+                                               dq.ptr, width, s * width, dk.ptr, width, s * width, dv.ptr, width, s * width,
+                                               b, heads, s, width // heads, scale))
+        return dq, dk, dv
+
+
+HipTensor.attention_supported = attention_supported
+
+
 @HipTensor.register_op()
 class layer_norm(Function):
     """ nn.LayerNorm over the last axis in one kernel (composite: nn.py:109-124); backward dx fused,

@@ -118,6 +118,70 @@ def test_fused_softmax(hip, shape, axis):
     assert e_fused <= 2 * e_composite + 1e-7, (e_fused, e_composite)
 
 
+def composite_attention(q, k, v, heads, scale):
+    """the model's own lines (examples/bert.py): head split by stride permutation, scores, scaled softmax, context"""
+    b, s, width = q.shape
+    d = width // heads
+    q4 = q.reshape(b, s, heads, d).transpose(0, 2, 1, 3)
+    k4 = k.reshape(b, s, heads, d).transpose(0, 2, 3, 1)
+    v4 = v.reshape(b, s, heads, d).transpose(0, 2, 1, 3)
+    probs = composite_softmax((q4 @ k4) * scale)
+    return (probs @ v4).transpose(0, 2, 1, 3).reshape(b, s, width), probs
+
+
+@pytest.mark.parametrize("b,s,heads,d", [(8, 128, 2, 64), (2, 32, 1, 64), (3, 96, 4, 32), (1, 64, 3, 32), (2, 64, 2, 64), (1, 128, 1, 32)])
+def test_fused_attention(hip, b, s, heads, d):
+    """one launch each way (csrc/attention.hip) against the composite tape: context, probabilities and the three input
+    gradients within 1e-5 (relative Frobenius) of a float64 run of the composite, and no further from it than twice the
+    composite's own float32 kernels; probabilities are rows of a softmax"""
+    rng = np.random.RandomState(7)
+    width = heads * d
+    scale = float(np.sqrt(d)) ** -1
+    q, k, v = (rng.uniform(-1.5, 1.5, (b, s, width)).astype(np.float32) for _ in range(3))
+    w = rng.uniform(-1, 1, (b, s, width)).astype(np.float32)
+    fused = [hip.from_numpy(x) for x in (q, k, v)]
+    plain = [hip.from_numpy(x) for x in (q, k, v)]
+    assert fused[0].attention_supported(heads)
+    out = fused[0].attention(fused[1], fused[2], heads=heads, scale=scale)
+    (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    out2, probs2 = composite_attention(*plain, heads, scale)
+    (out2 * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    with float64_tape():
+        ref = [CpuTensor.from_numpy(x.astype(np.float64)) for x in (q, k, v)]
+        out_r, probs_r = composite_attention(*ref, heads, scale)
+        (out_r * CpuTensor.from_numpy(w.astype(np.float64), requires_grad=False)).backward(allow_fill=True)
+    probs = out.attention_probs
+    assert probs.shape == (b, heads, s, s) and not probs.requires_grad
+    np.testing.assert_allclose(probs.numpy().sum(axis=-1), 1.0, rtol=1e-5)
+    for name, got, comp, want in [("context", out, out2, out_r), ("probs", probs, probs2, probs_r)] + \
+            [("d" + n, f.grad, c.grad, r.grad) for n, f, c, r in zip("qkv", fused, plain, ref)]:
+        e_fused, e_comp = rel_frobenius(got.numpy(), want.numpy()), rel_frobenius(comp.numpy(), want.numpy())
+        assert e_fused <= 1e-5, (name, e_fused, e_comp)
+        assert e_fused <= 2 * e_comp + 2e-7, (name, e_fused, e_comp)
+
+
+def test_fused_attention_takes_projection_outputs_as_they_lie(hip):
+    """q, k, v as column blocks of ONE (b, s, 3 * width) buffer (row pitch 3 * width): addressed in place, same values"""
+    rng = np.random.RandomState(8)
+    b, s, heads, d = 2, 64, 2, 32
+    width = heads * d
+    packed = rng.uniform(-1, 1, (b, s, 3 * width)).astype(np.float32)
+    w = rng.uniform(-1, 1, (b, s, width)).astype(np.float32)
+    t = hip.from_numpy(packed, requires_grad=False)
+    views = [hip(t.data, (b, s, width), t.strides, t.offset + i * width, t.dtype, requires_grad=True) for i in range(3)]
+    dense = [hip.from_numpy(np.ascontiguousarray(packed[:, :, i * width:(i + 1) * width])) for i in range(3)]
+    res = []
+    for qkv in (views, dense):
+        out = qkv[0].attention(qkv[1], qkv[2], heads=heads, scale=0.25)
+        (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        res.append([out.numpy(), out.attention_probs.numpy()] + [x.grad.numpy() for x in qkv])
+    for x, y in zip(*res):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(AssertionError, match="unsupported"):
+        hip.from_numpy(np.zeros((1, 48, 64), np.float32)).attention(hip.from_numpy(np.zeros((1, 48, 64), np.float32)),
+                                                                   hip.from_numpy(np.zeros((1, 48, 64), np.float32)), heads=1)
+
+
 @pytest.mark.parametrize("shape", [(4, 128), (2, 128, 128), (3, 5, 40), (9, 1000)])
 def test_fused_layernorm(hip, shape):
     import lightgrad_amd.nn as nn

@@ -61,7 +61,12 @@ class BertEmbedding(nn.Module):
         zeros, position_ids = self._constant_ids(input_ids.__class__, input_ids.shape)
         if token_type_ids is None:
             token_type_ids = zeros
-        e = self.word_embeddings(input_ids) + self.position_embeddings(position_ids) + self.token_type_embeddings(token_type_ids)
+        word, position, kind = self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight
+        if hasattr(word, "embedding_sum"):
+            # the backend's one-kernel form of the line below: three lookups and their sum
+            e = word.embedding_sum(position, kind, ids0=input_ids, ids1=position_ids, ids2=token_type_ids)
+        else:
+            e = self.word_embeddings(input_ids) + self.position_embeddings(position_ids) + self.token_type_embeddings(token_type_ids)
         return self.LayerNorm(e)
 
 
@@ -126,7 +131,12 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden, attention_mask=None):
         hidden, probs = self.attention(hidden, attention_mask)
-        hidden = self.output.dense(gelu(self.intermediate.dense(hidden)), residual=hidden)  # hidden + dense(...)
+        if hasattr(hidden, "feed_forward"):
+            # the backend's one-node form of the line below: gelu and residual in the products' epilogues, four launches for six
+            up, down = self.intermediate.dense, self.output.dense
+            hidden = hidden.feed_forward(up.weight, up.bias, down.weight, down.bias, hidden)
+        else:
+            hidden = self.output.dense(gelu(self.intermediate.dense(hidden)), residual=hidden)  # hidden + dense(...)
         return self.output.LayerNorm(hidden), probs
 
 

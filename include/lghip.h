@@ -222,6 +222,19 @@ int lg_gemm_addend_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                        const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                        const float* bias, const float* addend, int64_t ldadd);
 
+/* One matrix product with an activation applied where the result is made (small tiles):
+ *   act = LG_ACT_GELU      C = op(A) @ op(B) + bias (the pre-activation, kept for the backward) and aux[m][n] = gelu(C[m][n])
+ *                          - nn.Linear followed by the gelu of examples/bert.py:12 without the elementwise pass
+ *   act = LG_ACT_GELU_BWD  C = (op(A) @ op(B)) * gelu'(aux[m][n]), aux the pre-activation saved by the forward: the input
+ *                          gradient of the NEXT Linear (dot.backward, cpu/ops.py:116) multiplied by the gelu derivative
+ *                          in the same launch (bias must be NULL)
+ * aux is [M, N] with row pitch ldaux.  The same expressions as the elementwise gelu kernels, bit for bit. */
+#define LG_ACT_GELU 1
+#define LG_ACT_GELU_BWD 2
+int lg_gemm_act_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                    const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                    const float* bias, int act, float* aux, int64_t ldaux);
+
 /* lg_gemm_f32 over a TWO-level batch: matrix (o, i) of operand X starts at X + o*strideX_outer + i*strideX_inner.
  * One launch for attention-shaped products whose (batch, head) dims do not collapse into one stride after the head
  * split `reshape(b, s, h, d).transpose(0, 2, 1, 3)` (examples/bert.py:70-95; the reference's kernel is launched per
@@ -406,6 +419,14 @@ int lg_layernorm_param_grads_f32(const float* g, const float* xhat, float* dw, f
  * numpy `grad[idx] = g`, cpu/ops.py:245, keeps only the last one, and its BERT example drops the gradient). */
 int lg_gather_rows_f32(const float* table, const void* ids, int id_itemsize, float* out,
                        int64_t n_ids, int64_t row_len, int64_t table_rows);
+/* out[i, :] = (t0[ids0[i % n0], :] + t1[ids1[i % n1], :]) + t2[ids2[i % n2], :] - three lookups and their sum in one pass
+ * (BERT's word + position + token-type embeddings, examples/bert.py:36-40: three lookups and two kernels.atom adds).  n_k ids
+ * for table k (n_k divides n_out: an id tensor broadcast over leading axes), rows_k rows in table k; ids all int32 or all
+ * int64.  Sums in the order written, each rounded to fp32.  Out-of-range ids as in lg_gather_rows_f32. */
+int lg_gather_sum3_rows_f32(const float* t0, const void* ids0, int64_t n0, int64_t rows0,
+                            const float* t1, const void* ids1, int64_t n1, int64_t rows1,
+                            const float* t2, const void* ids2, int64_t n2, int64_t rows2,
+                            int id_itemsize, float* out, int64_t n_out, int64_t row_len);
 int lg_scatter_add_rows_f32(const float* grad_out, const void* ids, int id_itemsize, float* grad_table,
                             int64_t n_ids, int64_t row_len, int64_t table_rows);
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("LIGHTGRAD_HIP_LIB") or os.path.join(_PKG_DIR, "liblgh
 COMM_LIB_PATH = os.path.join(_PKG_DIR, "liblghip_comm.so")
 
 # lg_ew op ids (lghip.h: lg_ew_op_t)
+ACT_GELU, ACT_GELU_BWD = 1, 2       # lg_gemm_act_f32
 EW_COPY, EW_NEG, EW_EXP, EW_LOG, EW_RELU, EW_SIGMOID, EW_TANH, EW_SIN, EW_COS, EW_SQRT, EW_GELU = range(11)
 (EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_POW, EW_RELU_BWD, EW_SIGMOID_BWD, EW_TANH_BWD, EW_LOG_BWD,
  EW_SIN_BWD, EW_COS_BWD, EW_EQ, EW_GE, EW_BIAS_RELU, EW_GELU_BWD) = range(32, 47)
@@ -83,6 +84,8 @@ PROTOTYPES = {
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_gemm_addend_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_void_p, c_int64]),
+    "lg_gemm_act_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                               c_void_p, c_int, c_void_p, c_int64]),
     "lg_gemm_fused_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
     "lg_gemm_batched2_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
@@ -111,6 +114,7 @@ PROTOTYPES = {
     "lg_put_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_uint64]),
     "lg_scatter_add_axis_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "lg_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
+    "lg_gather_sum3_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64] * 3 + [c_int, c_void_p, c_int64, c_int64]),
     "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
 }
 

@@ -525,6 +525,24 @@ def _gemm_fused(a, b, bias=None, accumulate_into=None, overwrite=False, rowsum_i
     return out, rowsum
 
 
+def _gemm_act(a, b, act, aux=None, bias=None):
+    """2-D a @ b through lg_gemm_act_f32.  act = ACT_GELU: returns (pre, gelu(pre)) with pre = a @ b + bias.
+    act = ACT_GELU_BWD: returns ((a @ b) * gelu'(aux), None), aux the pre-activation the forward kept."""
+    _require_f32(a, b)
+    (M, K), (K2, N) = a._shape, b._shape
+    assert K == K2 and M > 0 and N > 0 and K > 0
+    ma, mb = _as_mat(a), _as_mat(b)
+    out = HipTensor.empty((M, N))
+    if act == _l.ACT_GELU:
+        aux = HipTensor.empty((M, N))
+        assert bias is None or (bias._shape == (N,) and bias.is_contiguous() and bias._dtype == _F32)
+    else:
+        assert bias is None and aux._shape == (M, N) and aux.is_contiguous() and aux._dtype == _F32
+    _l.check(_l.lib().lg_gemm_act_f32(1 if ma.colmajor else 0, 1 if mb.colmajor else 0, M, N, K, ma.t.ptr, ma.ld, mb.t.ptr, mb.ld,
+                                      out.ptr, N, bias.ptr if bias is not None else None, act, aux.ptr, N))
+    return out, (aux if act == _l.ACT_GELU else None)
+
+
 def _lazy_relu_input(x):
     """the pre-activation t if x is a still-lazy relu(t) that a 2-D GEMM can read in its place, else None"""
     if x._data is None and x._lazy_source is not None and x._lazy_source[0] == "relu" and len(x._shape) == 2:
@@ -980,25 +998,69 @@ class getitem(Function):
             _scatter_add(grad, idx, out_grad)
             return grad
         if isinstance(idx, HipTensor):
-            # repeated ids accumulate.  A leaf table that already owns a gradient buffer (an embedding matrix after
-            # zero_grad) gets the rows added in place: no table-sized zero fill, no table-sized `grad +=`
-            table = ctx._parents[0]
-            acc = table._grad_accumulator() if table.requires_grad else None
-            if acc is not None and acc.is_contiguous() and acc._dtype == _F32:
-                if table._consume_zero_pending():
-                    acc.fill(0)
-                if GradGroup.usable_for(table) and idx.numel() <= 4096:
-                    ids_c, g_c = idx.contiguous(), out_grad.contiguous()        # (copies, if any, happen now, on the main chain)
-                    with GradGroup.issue(reads=(ids_c, g_c), writes=(acc,)):    # queued: leaves with the LayerNorm gradients
-                        _scatter_add_rows(shape, ids_c, g_c, into=acc)
-                else:
-                    _scatter_add_rows(shape, idx, out_grad, into=acc)
-                table._notify_grad_written()
-                return None
-            return _scatter_add_rows(shape, idx, out_grad)
+            return _table_rows_grad(ctx._parents[0], shape, idx, out_grad)
         grad = HipTensor.zeros(shape, dtype=out_grad._dtype, requires_grad=False)
         grad[idx] = out_grad
         return grad
+
+
+def _table_rows_grad(table, shape, idx, out_grad):
+    """gradient of `table[idx]` (idx an integer tensor on the first axis): repeated ids accumulate.  A leaf table that already
+    owns a gradient buffer (an embedding matrix after zero_grad) gets the rows added in place - no table-sized zero fill, no
+    table-sized `grad +=` - and None is returned; otherwise the gradient tensor."""
+    acc = table._grad_accumulator() if table.requires_grad else None
+    if acc is not None and acc.is_contiguous() and acc._dtype == _F32:
+        if table._consume_zero_pending():
+            acc.fill(0)
+        if GradGroup.usable_for(table) and idx.numel() <= 4096:
+            ids_c, g_c = idx.contiguous(), out_grad.contiguous()        # (copies, if any, happen now, on the main chain)
+            with GradGroup.issue(reads=(ids_c, g_c), writes=(acc,)):    # queued: leaves with the LayerNorm gradients
+                _scatter_add_rows(shape, ids_c, g_c, into=acc)
+        else:
+            _scatter_add_rows(shape, idx, out_grad, into=acc)
+        table._notify_grad_written()
+        return None
+    return _scatter_add_rows(shape, idx, out_grad)
+
+
+@HipTensor.register_op()
+class embedding_sum(Function):
+    """ (t0[ids0] + t1[ids1]) + t2[ids2] in one pass: the word, position and token-type lookups of a BERT embedding layer and
+    their two additions (reference examples/bert.py:36-40; there on the CPU).  The id tensors go in by keyword (they take no
+    gradient); ids0 has the full shape, ids1 / ids2 may lack leading axes (position ids shared by the batch).  Same bits as the
+    three `table[ids]` and two `+` of the tape; the backward is theirs too: rows added into each table's gradient. """
+    def forward(ctx, t0, t1, t2, ids0=None, ids1=None, ids2=None):
+        _require_f32(t0, t1, t2)
+        ids = (ids0, ids1, ids2)
+        tables = tuple(t.contiguous() for t in (t0, t1, t2))
+        assert all(isinstance(i, HipTensor) and i._dtype == ids0._dtype for i in ids) and ids0._dtype in (np.dtype(np.int32), np.dtype(np.int64)), \
+            "embedding_sum: the three id tensors must be int32 or int64 tensors of one dtype"
+        assert all(len(t._shape) == 2 and t._shape[1] == t0._shape[1] for t in tables), "embedding_sum: tables of one row length"
+        for i in ids[1:]:
+            assert len(i._shape) <= len(ids0._shape) and ids0._shape[len(ids0._shape) - len(i._shape):] == i._shape, \
+                "embedding_sum: ids of shape %s do not broadcast against %s by leading axes" % (i._shape, ids0._shape)
+        ids = tuple(i.contiguous() for i in ids)
+        out = HipTensor.empty(ids0._shape + (t0._shape[1],))
+        args = []
+        for t, i in zip(tables, ids):
+            args += [t.ptr, i.ptr, i.numel(), t._shape[0]]
+        _l.check(_l.lib().lg_gather_sum3_rows_f32(*args, ids0._dtype.itemsize, out.ptr, ids0.numel(), t0._shape[1]))
+        ctx.save_for_backward(ids, tuple(t._shape for t in tables))
+        return out
+
+    def backward(ctx, out_grad):
+        ids, shapes = ctx.get_saved_tensors()
+        grads = []
+        for table, shape, i in zip(ctx._parents[:3], shapes, ids):
+            if not table.requires_grad:
+                grads.append(None)
+                continue
+            g = out_grad
+            if i._shape != ids[0]._shape:                               # ids shared by leading axes: their rows' gradients add up
+                lead = len(ids[0]._shape) - len(i._shape)
+                g = g.sum(axis=tuple(range(lead)), keepdims=False)
+            grads.append(_table_rows_grad(table, shape, i, g))
+        return tuple(grads)
 
 
 @HipTensor.register_op("__setitem__")
@@ -1326,6 +1388,62 @@ class linear(Function):
                 _gemm(g2, weight, accumulate_into=flat)
             return (None,)
         return (_gemm(g2, weight).reshape(*x._shape),)
+
+
+@HipTensor.register_op()
+class feed_forward(Function):
+    """ dense2(gelu(dense1(x))) + residual in one tape node - the position-wise block of a transformer layer (reference
+    examples/bert.py:104-118: Linear, gelu, Linear, `+ hidden`): the gelu rides in the first product's epilogue, the residual in
+    the second's, and in the backward the gelu derivative in the epilogue of the product that makes the gradient it scales.
+    Four launches instead of six, the values of the separate ops bit for bit.  Weights as nn.Linear holds them ((out, in));
+    the weight / bias gradients take the routes of `linear` (queued in a deep backward pass, else with dx). """
+    def forward(ctx, x, w1, b1, w2, b2, residual=None):
+        _require_f32(x, w1, b1, w2, b2)
+        assert b1 is not None and b2 is not None and x.numel() > 0
+        x2 = x.reshape(-1, x._shape[-1])
+        pre, act = _gemm_act(x2, _swap_last(w1), _l.ACT_GELU, bias=b1.contiguous())
+        if residual is not None:
+            assert residual._shape == x._shape[:-1] + (w2._shape[0],)
+            res2 = residual.contiguous()
+            out = _gemm(act, _swap_last(w2), bias=b2, addend=HipTensor(res2.data, (x2._shape[0], w2._shape[0]), None, res2._offset, res2._dtype))
+        else:
+            out = _gemm(act, _swap_last(w2), bias=b2)
+        ctx.save_for_backward(x, pre, act)
+        return out.reshape(*(x._shape[:-1] + (w2._shape[0],)))
+
+    def backward(ctx, out_grad):
+        x, pre, act = ctx.get_saved_tensors()
+        _, w1, b1, w2, b2 = ctx._parents[:5]
+        g2 = out_grad.reshape(-1, w2._shape[0]).contiguous()
+        x2 = x.reshape(-1, x._shape[-1])
+        grads = {}
+
+        def weight_side(name_w, name_b, inp, weight, bias, g):
+            want_db = bias.requires_grad
+            acc_w = weight._grad_accumulator() if weight.requires_grad else None
+            acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+            acc_b = bias._grad_accumulator() if want_db else None
+            acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+            if acc_w is not None and (not want_db or acc_b is not None) and GradGroup.usable_for(weight, bias):
+                with GradGroup.issue(reads=(g, inp), writes=(acc_w, acc_b)):
+                    grads[name_w], grads[name_b] = linear._weight_products(inp, weight, bias, want_db, g, acc_w, acc_b)
+            else:
+                grads[name_w], grads[name_b] = linear._weight_products(inp, weight, bias, want_db, g, acc_w, acc_b)
+        weight_side("w2", "b2", act, w2, b2, g2)
+        dpre, _ = _gemm_act(g2, w2, _l.ACT_GELU_BWD, aux=pre)        # (g @ W2) * gelu'(pre)
+        weight_side("w1", "b1", x2, w1, b1, dpre)
+        residual = ctx._parents[5] if len(ctx._parents) > 5 else None
+        res_grad = out_grad
+        if residual is x and x.requires_grad and x._ctx is not None and x._view_of_leaf is None:
+            # the block's input is its residual: out_grad goes to it first, and the product below adds dx to it in its
+            # epilogue (linear._input_product) instead of a separate `grad + dx` pass
+            x.add_grad(out_grad)
+            res_grad = None
+        dx, = linear._input_product(x, w1, dpre)
+        out = (dx, grads["w1"], grads["b1"], grads["w2"], grads["b2"])
+        if residual is not None:
+            out = out + (res_grad,)
+        return out
 
 
 def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):

@@ -13,6 +13,7 @@
 // of cpu/ops.py (cited per functor).  The code generator of opencl/kernels.py:24-195 is
 // not reproduced: ops are compiled ahead of time for gfx950.
 #include "common.h"
+#include "gelu_common.h"
 
 namespace lg {
 
@@ -34,10 +35,8 @@ LG_OP(OpTanh, 1, 1, out[0] = tanhf(in[0]);)
 LG_OP(OpSin, 1, 1, out[0] = sinf(in[0]);)
 LG_OP(OpCos, 1, 1, out[0] = cosf(in[0]);)
 LG_OP(OpSqrt, 1, 1, out[0] = sqrtf(in[0]);)
-// tanh-approximated gelu, evaluated in the order of the reference's expression (examples/bert.py:12):
-//   0.5 * x * (1.0 + (x * 0.7978845608 * (1.0 + 0.044715 * x * x)).tanh())
-__device__ __forceinline__ float gelu_inner(float x) { return (x * 0.7978845608f) * (1.0f + (0.044715f * x) * x); }
-LG_OP(OpGelu, 1, 1, const float x = in[0]; out[0] = (0.5f * x) * (1.0f + tanhf(gelu_inner(x)));)
+// tanh-approximated gelu (gelu_common.h: shared with the GEMM epilogues)
+LG_OP(OpGelu, 1, 1, out[0] = gelu_value(in[0]);)
 
 LG_OP(OpAdd, 2, 1, out[0] = in[0] + in[1];)
 LG_OP(OpSub, 2, 1, out[0] = in[0] - in[1];)
@@ -50,10 +49,8 @@ LG_OP(OpTanhBwd, 2, 1, out[0] = (1.0f - in[0] * in[0]) * in[1];)
 LG_OP(OpLogBwd, 2, 1, out[0] = (1.0f / in[0]) * in[1];)
 LG_OP(OpSinBwd, 2, 1, out[0] = cosf(in[0]) * in[1];)
 LG_OP(OpCosBwd, 2, 1, out[0] = -sinf(in[0]) * in[1];)
-// a = x, b = g: d/dx [0.5 x (1 + tanh u)] = 0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) u',  u' = 0.7978845608 (1 + 3*0.044715 x^2)
-LG_OP(OpGeluBwd, 2, 1, const float x = in[0]; const float th = tanhf(gelu_inner(x));
-      const float du = 0.7978845608f * (1.0f + 0.134145f * x * x);
-      out[0] = in[1] * (0.5f * (1.0f + th) + (0.5f * x) * (1.0f - th * th) * du);)
+// a = x, b = g
+LG_OP(OpGeluBwd, 2, 1, out[0] = gelu_grad(in[0], in[1]);)
 LG_OP(OpEq, 2, 1, out[0] = in[0] == in[1] ? 1.0f : 0.0f;)
 LG_OP(OpGe, 2, 1, out[0] = in[0] >= in[1] ? 1.0f : 0.0f;)
 

@@ -27,6 +27,7 @@
 // Reference semantics: `dot` = numpy matmul (cpu/ops.py:107-116); the tiled OpenCL kernel with its
 // pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
 #include "common.h"
+#include "gelu_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -91,7 +92,13 @@ struct GemmArgs {
     int     k_tail;         // K % 4 != 0: K-contiguous float4s of the last tile carry elements beyond K, zeroed before LDS
     // relu folded into its consumers (the tape's relu stays lazy, autograd/hip/ops.py): op(A) / op(B) are passed through
     // np.maximum(., 0) on their way to LDS
-    int     relu_a, relu_b;
+    short   relu_a, relu_b;
+    // an activation in the epilogue (small tiles only; lg_gemm_act_f32).  act = 1: C keeps the pre-activation (product + bias)
+    // and aux[m][n] receives gelu of it.  act = 2: the product is multiplied by gelu'(aux[m][n]) - the gelu backward of the
+    // tape applied to the input gradient where it is made.  aux: [M, N] with row pitch ldadd (never together with an addend;
+    // the argument block of the group launch has no room for a pitch of its own).
+    int     act;
+    float*  aux;
 #ifdef LG_GEMM_TIMELINE
     // experiments build only (make timeline; tools/gemm_timeline.py): 8 timestamps of the 100 MHz wall clock per workgroup
     unsigned long long* tl;
@@ -502,7 +509,8 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      float* C, int64_t ldc, int64_t strideC,
                      int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0,
                      int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0,
-                     int relu_a = 0, int relu_b = 0, const float* addend = nullptr, int64_t ldadd = 0) {
+                     int relu_a = 0, int relu_b = 0, const float* addend = nullptr, int64_t ldadd = 0,
+                     int act = 0, float* aux = nullptr, int64_t ldaux = 0) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -552,7 +560,11 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     g.rowsum_accumulate = rowsum_accumulate;
     g.k_tail = (K % 4 != 0) ? 1 : 0;
     g.relu_a = relu_a; g.relu_b = relu_b;
-    const bool fused_extras = rowsum != nullptr || relu_a || relu_b;     // not compiled into the 256x256 tile
+    g.act = act; g.aux = aux;
+    if (act) g.ldadd = ldaux;
+    LG_ARG(act == 0 || (batch == 1 && rowsum == nullptr && addend == nullptr && aux != nullptr && ldaux >= N && K > 0 && (act == 1 || act == 2)),
+           "lg_gemm_act_f32: one matrix product with K > 0, act 1 or 2, aux [M, N] with ldaux >= N");
+    const bool fused_extras = rowsum != nullptr || relu_a || relu_b || act != 0;     // not compiled into the 256x256 tile
     LG_ARG(!(relu_a || relu_b) || batch == 1, "lg_gemm_fused_f32: one matrix product");
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
@@ -747,6 +759,15 @@ extern "C" int lg_gemm_addend_f32(int transA, int transB, int64_t M, int64_t N, 
                                   const float* bias, const float* addend, int64_t ldadd) {
     LG_ARG(addend != nullptr, "lg_gemm_addend_f32: addend is NULL");
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, 0, bias, nullptr, 0, 1, 0, 0, 0, 0, 0, addend, ldadd);
+}
+
+extern "C" int lg_gemm_act_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                               const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                               const float* bias, int act, float* aux, int64_t ldaux) {
+    LG_ARG(act == LG_ACT_GELU || act == LG_ACT_GELU_BWD, "lg_gemm_act_f32: unknown activation id %d", act);
+    LG_ARG(act == LG_ACT_GELU || bias == nullptr, "lg_gemm_act_f32: the backward form takes no bias");
+    return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, 0, bias, nullptr, 0, 1, 0, 0, 0, 0, 0, nullptr, 0,
+                     act, aux, ldaux);
 }
 
 extern "C" int lg_gemm_group_colsum_f32(const float* in, int64_t ld, int64_t rows, int64_t cols, float* out, int accumulate) {

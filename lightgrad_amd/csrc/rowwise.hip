@@ -470,6 +470,35 @@ __global__ void __launch_bounds__(256) gather_rows(const float* __restrict__ tab
     }
 }
 
+// out[i, :] = (t0[ids0[i % n0], :] + t1[ids1[i % n1], :]) + t2[ids2[i % n2], :]: the three lookups of a BERT embedding layer and
+// their two additions (examples/bert.py:36-40: word + position + token type, five kernels) as one pass; the sums in that order,
+// each rounded to fp32 - the values of the separate kernels.  `i % n`: an id tensor that is broadcast over leading axes.
+struct GatherSum3 {
+    const float* table[3];
+    const void*  ids[3];
+    int64_t      n[3], rows[3];
+};
+template <typename IdT>
+__global__ void __launch_bounds__(256) gather_sum3_rows(GatherSum3 a, float* __restrict__ out, int64_t n_out, int64_t row_len, int* status) {
+    const int64_t total = n_out * row_len;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / row_len, c = e - i * row_len;
+        float v[3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int64_t r = int64_t(static_cast<const IdT*>(a.ids[k])[i % a.n[k]]);
+            if (r < 0) r += a.rows[k];
+            const bool in = r >= 0 && r < a.rows[k];
+            v[k] = in ? a.table[k][r * row_len + c] : __builtin_nanf("");
+            ok = ok && in;
+        }
+        if (!ok) __hip_atomic_fetch_or(status, LG_STATUS_BAD_INDEX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        out[e] = (v[0] + v[1]) + v[2];
+    }
+}
+
 template <typename IdT>
 __global__ void __launch_bounds__(256) scatter_add_rows(const float* __restrict__ grad_out, const IdT* __restrict__ ids,
                                                         float* __restrict__ grad_table, int64_t n_ids, int64_t row_len, int64_t table_rows,
@@ -713,6 +742,25 @@ extern "C" int lg_gather_rows_f32(const float* table, const void* ids, int id_it
         hipLaunchKernelGGL(gather_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int32_t*>(ids), out, n_ids, row_len, table_rows, rt().status_dev);
     else
         hipLaunchKernelGGL(gather_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, table, static_cast<const int64_t*>(ids), out, n_ids, row_len, table_rows, rt().status_dev);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_gather_sum3_rows_f32(const float* t0, const void* ids0, int64_t n0, int64_t rows0,
+                                       const float* t1, const void* ids1, int64_t n1, int64_t rows1,
+                                       const float* t2, const void* ids2, int64_t n2, int64_t rows2,
+                                       int id_itemsize, float* out, int64_t n_out, int64_t row_len) {
+    LG_REQUIRE_INIT();
+    LG_ARG(id_itemsize == 4 || id_itemsize == 8, "lg_gather_sum3_rows_f32: ids must be int32 or int64");
+    LG_ARG(n_out >= 0 && row_len >= 0 && rows0 >= 0 && rows1 >= 0 && rows2 >= 0, "lg_gather_sum3_rows_f32: bad shape");
+    if (n_out == 0 || row_len == 0) return LG_OK;
+    LG_ARG(t0 && t1 && t2 && ids0 && ids1 && ids2 && out, "lg_gather_sum3_rows_f32: NULL pointer");
+    LG_ARG(n0 >= 1 && n1 >= 1 && n2 >= 1 && n_out % n0 == 0 && n_out % n1 == 0 && n_out % n2 == 0,
+           "lg_gather_sum3_rows_f32: every id count must divide the %lld output rows", (long long)n_out);
+    GatherSum3 a{{t0, t1, t2}, {ids0, ids1, ids2}, {n0, n1, n2}, {rows0, rows1, rows2}};
+    const unsigned grid = stream_grid(n_out * row_len);
+    if (id_itemsize == 4) hipLaunchKernelGGL(gather_sum3_rows<int32_t>, dim3(grid), dim3(256), 0, rt().stream, a, out, n_out, row_len, rt().status_dev);
+    else                  hipLaunchKernelGGL(gather_sum3_rows<int64_t>, dim3(grid), dim3(256), 0, rt().stream, a, out, n_out, row_len, rt().status_dev);
     LG_CHECK_LAUNCH();
     return LG_OK;
 }

@@ -259,6 +259,70 @@ def test_embedding_gather_and_scatter_add(hip):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=str((n_ids, hot)))
 
 
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+def test_embedding_sum_is_the_three_lookups_and_two_adds(hip, dtype):
+    """word + position + token-type embeddings in one pass: the bits of the composite line of examples/bert.py, values and
+    the three table gradients (position ids shared by the batch: their rows' gradients are summed over it first)"""
+    rng = np.random.RandomState(6)
+    b, s, width = 3, 10, 12
+    tables = [rng.uniform(-1, 1, (n, width)).astype(np.float32) for n in (40, 16, 2)]
+    ids = rng.randint(0, 40, (b, s)).astype(dtype)
+    ids[1, :3] = 5
+    ids[2, 0] = -1
+    pos = np.arange(s, dtype=dtype)
+    kind = rng.randint(0, 2, (b, s)).astype(dtype)
+    w = rng.uniform(-1, 1, (b, s, width)).astype(np.float32)
+    fused, plain = [hip.from_numpy(t) for t in tables], [hip.from_numpy(t) for t in tables]
+    i0, i1, i2 = (hip.from_numpy(x, requires_grad=False) for x in (ids, pos, kind))
+    out = fused[0].embedding_sum(fused[1], fused[2], ids0=i0, ids1=i1, ids2=i2)
+    out2 = plain[0][i0] + plain[1][i1] + plain[2][i2]
+    np.testing.assert_array_equal(out.numpy(), out2.numpy())
+    np.testing.assert_array_equal(out.numpy(), (tables[0][ids] + tables[1][pos]) + tables[2][kind])
+    (out * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    (out2 * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    for f, q in zip(fused, plain):
+        np.testing.assert_allclose(f.grad.numpy(), q.grad.numpy(), rtol=1e-6, atol=1e-6)
+    bad = hip.from_numpy(np.full((b, s), 40, dtype), requires_grad=False)
+    out = fused[0].embedding_sum(fused[1], fused[2], ids0=bad, ids1=i1, ids2=i2)
+    with pytest.raises(IndexError):
+        out.numpy()
+
+
+@pytest.mark.parametrize("rows,width,inner", [((8, 128), 128, 512), ((3, 10), 36, 52), ((70,), 64, 64)])
+def test_feed_forward_block_against_the_separate_ops(hip, rows, width, inner):
+    """dense2(gelu(dense1(x))) + x as one node (gelu and its derivative in GEMM epilogues) against Linear, gelu, Linear, add
+    on the same backend: output and all five gradients (the same elementwise expressions; the products may split K differently,
+    so to rounding), and against a float64 run of the composite"""
+    import lightgrad_amd.nn as nn
+    rng = np.random.RandomState(9)
+    x = rng.uniform(-1, 1, rows + (width,)).astype(np.float32)
+    w = rng.uniform(-1, 1, rows + (width,)).astype(np.float32)
+    params = [rng.uniform(-0.3, 0.3, s).astype(np.float32) for s in ((inner, width), (inner,), (width, inner), (width,))]
+    res = []
+    for fused in (True, False):
+        tx = hip.from_numpy(x)
+        w1, b1, w2, b2 = (hip.from_numpy(p) for p in params)
+        if fused:
+            y = tx.feed_forward(w1, b1, w2, b2, tx)
+        else:
+            up, down = nn.Linear(width, inner), nn.Linear(inner, width)
+            up.weight, up.bias, down.weight, down.bias = w1, b1, w2, b2
+            y = down(up(tx).gelu(), residual=tx)
+        (y * hip.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        res.append([y.numpy()] + [t.grad.numpy() for t in (tx, w1, b1, w2, b2)])
+    for name, a, b in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), *res):
+        assert rel_frobenius(a, b) <= 2e-6, (name, rel_frobenius(a, b))
+    with float64_tape():
+        cx = CpuTensor.from_numpy(x.astype(np.float64))
+        cw1, cb1, cw2, cb2 = (CpuTensor.from_numpy(p.astype(np.float64)) for p in params)
+        h = cx @ cw1.transpose(1, 0) + cb1
+        h = 0.5 * h * (1.0 + (h * 0.7978845608 * (1.0 + 0.044715 * h * h)).tanh())
+        y = h @ cw2.transpose(1, 0) + cb2 + cx
+        (y * CpuTensor.from_numpy(w.astype(np.float64), requires_grad=False)).backward(allow_fill=True)
+    for name, got, want in zip(("y", "dx", "dw1", "db1", "dw2", "db2"), res[0], [y.numpy()] + [t.grad.numpy() for t in (cx, cw1, cb1, cw2, cb2)]):
+        assert rel_frobenius(got, want) <= 1e-5, (name, rel_frobenius(got, want))
+
+
 def test_parameter_gradients_accumulate_in_place(hip):
     """second backward pass into existing gradient buffers (what a training step does after zero_grad): LayerNorm's
     fused dw/db launch and the embedding scatter-add write into the parameters' buffers and must ADD - after an eager

@@ -3,6 +3,7 @@ accumulate mode through the raw C ABI, and BASELINE's 4096^2 forward+backward th
 properties.  Error metric: relative Frobenius error against float64 numpy <= 1e-5."""
 import ctypes
 import numpy as np
+import lightgrad_amd as light
 import pytest
 import np_oracle as O
 

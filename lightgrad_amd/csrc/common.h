@@ -44,6 +44,9 @@ bool gemm_group_is_open();
 int gemm_group_flush_pending();
 int ln_group_flush_pending();
 bool ln_group_writes(const void* ptr);
+struct TailGroup;
+bool tail_take(TailGroup* out);       // rowwise.hip: the queued LayerNorm / scatter jobs as one argument block ...
+int tail_taken();                     // ... and, once launched, out of the queue
 
 // p2p.hip: what the first wait of the peer-window exchange that gave up was waiting for
 void p2p_describe_timeout(char* out, size_t len);

@@ -28,6 +28,7 @@
 // pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
 #include "common.h"
 #include "gelu_common.h"
+#include "tail_jobs.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -181,9 +182,39 @@ __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, Ge
 // them launch, prologue, split-K hand-off and epilogue, with a handful of workgroups on a 256-CU chip; queued during the
 // backward pass and launched together at its end they cost what the largest one costs.
 constexpr int kGroupMax = 14;
+// what a queued product needs of GemmArgs (one matrix, no bias / addend / activation / relu): the group's argument block has
+// to hold 14 of them AND the jobs that ride along, within the 4 KiB a kernel may take
+struct GroupProduct {
+    const float* A;
+    const float* B;
+    float*       C;
+    float*       W;
+    int*         tickets;
+    float*       rowsum;
+    int64_t      M, N, K, lda, ldb, ldc, k_per_slice;
+    int          tiles_m, tiles_n, nwg, accumulate, group_m, k_slices, rowsum_accumulate, k_tail;
+    FastDiv      div_per_batch, div_slices, div_gspan, div_group, div_last_group, div_batch_inner;
+};
+static GroupProduct pack_product(const GemmArgs& g) {
+    return GroupProduct{g.A, g.B, g.C, g.W, g.tickets, g.rowsum, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.k_per_slice,
+                        g.tiles_m, g.tiles_n, g.nwg, g.accumulate, g.group_m, g.k_slices, g.rowsum_accumulate, g.k_tail,
+                        g.div_per_batch, g.div_slices, g.div_gspan, g.div_group, g.div_last_group, g.div_batch_inner};
+}
+__device__ __forceinline__ GemmArgs unpack_product(const GroupProduct& p) {
+    GemmArgs g{};
+    g.A = p.A; g.B = p.B; g.C = p.C; g.W = p.W; g.tickets = p.tickets; g.rowsum = p.rowsum;
+    g.M = p.M; g.N = p.N; g.K = p.K; g.lda = p.lda; g.ldb = p.ldb; g.ldc = p.ldc; g.k_per_slice = p.k_per_slice;
+    g.tiles_m = p.tiles_m; g.tiles_n = p.tiles_n; g.nwg = p.nwg; g.accumulate = p.accumulate; g.group_m = p.group_m;
+    g.k_slices = p.k_slices; g.rowsum_accumulate = p.rowsum_accumulate; g.k_tail = p.k_tail;
+    g.div_per_batch = p.div_per_batch; g.div_slices = p.div_slices; g.div_gspan = p.div_gspan; g.div_group = p.div_group;
+    g.div_last_group = p.div_last_group; g.div_batch_inner = p.div_batch_inner;
+    g.batch_inner = 1;
+    return g;
+}
+
 struct GemmGroup {
-    GemmArgs p[kGroupMax];
-    int      first[kGroupMax + 1];      // first workgroup of each product (after the column-sum workgroups); first[count] = all of them
+    GroupProduct p[kGroupMax];
+    int      first[kGroupMax + 1];      // first workgroup of each product (after the other roles' workgroups); first[count] = all of them
     int      count;
     // one more job may ride along: column sums of a dense [rows, cols] matrix - the bias gradient of a Linear whose row-sum
     // column would cost a whole extra tile column in its weight-gradient product (BERT's decoder: db = column sums of the
@@ -193,6 +224,10 @@ struct GemmGroup {
     float*       cs_out;
     int64_t      cs_rows, cs_cols, cs_ld;
     int          cs_accumulate, cs_wgs;
+    // and the LayerNorm parameter gradients / embedding scatter-adds queued beside the products (tail_jobs.h): tail_wgs
+    // workgroups at the end of the grid
+    int          tail_wgs;
+    TailGroup    tail;
 };
 
 static_assert(sizeof(GemmGroup) <= 4096, "the group travels as kernel arguments");
@@ -225,9 +260,15 @@ __global__ void __launch_bounds__(256) sgemm_group_wgrad(GemmGroup grp) {
         return;
     }
     const int bid = int(blockIdx.x) - grp.cs_wgs;
+    if (bid >= grp.first[grp.count]) {
+        // LayerNorm parameter gradients / embedding scatter-adds, BEHIND the products: they take the slots the last products
+        // leave (in front of them they held every CU for their ~15 us first: 118 us for the launch instead of 102 + 34 apart)
+        tail_group_body(grp.tail, bid - grp.first[grp.count]);
+        return;
+    }
     int which = 0;
     while (which + 1 < grp.count && bid >= grp.first[which + 1]) ++which;      // uniform: scalar loads
-    const GemmArgs& g = grp.p[which];
+    const GemmArgs g = unpack_product(grp.p[which]);
 #define LG_TILE_OWNS_LDS 0
 #define LG_TILE_BID (bid - grp.first[which])
 #include "gemm_tile_body.inc"
@@ -324,6 +365,7 @@ struct GroupState {
     int       active = 0;
     int       count = 0;
     int64_t   tiles = 0;          // tickets handed to the queued products
+    GemmArgs  queued[kGroupMax];  // the products as prepared; packed into grp when they leave
     GemmGroup grp;
 };
 static GroupState& group_state() { static GroupState s; return s; }
@@ -340,7 +382,7 @@ static int group_flush() {
     }
     int rc = LG_OK;
     if (G.count == 1 && G.grp.cs_wgs == 0) {
-        pair_launch_single(G.grp.p[0], 0);
+        pair_launch_single(G.queued[0], 0);
     } else {
         // small products first: theirs are the long dependency chains (few workgroups, split-K hand-off and fold), a product
         // with hundreds of tiles (BERT's decoder) fills the chip behind them
@@ -348,14 +390,24 @@ static int group_flush() {
         int n = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int i = 0; i < G.count; ++i)
-                if ((G.grp.p[i].nwg > 256) == (pass == 1)) sorted[n++] = G.grp.p[i];
+                if ((G.queued[i].nwg > 256) == (pass == 1)) sorted[n++] = G.queued[i];
         G.grp.first[0] = 0;
-        for (int i = 0; i < G.count; ++i) { G.grp.p[i] = sorted[i]; G.grp.first[i + 1] = G.grp.first[i] + sorted[i].nwg; }
+        for (int i = 0; i < G.count; ++i) { G.queued[i] = sorted[i]; G.grp.p[i] = pack_product(sorted[i]); G.grp.first[i + 1] = G.grp.first[i] + sorted[i].nwg; }
         G.grp.count = G.count;
-        hipLaunchKernelGGL((sgemm_group_wgrad<kSmallTilePrefetch>), dim3(G.grp.cs_wgs + G.grp.first[G.count]), dim3(256), 0, rt().stream, G.grp);
+        // the LayerNorm parameter gradients and embedding scatter-adds queued beside the products ride in this launch - unless
+        // one of them writes where a product writes (a tied table: its scatter must ADD to what the product stores, in call order)
+        bool ride = true;
+        for (int i = 0; i < G.count; ++i) ride = ride && !ln_group_writes(G.queued[i].C) && !ln_group_writes(G.queued[i].rowsum);
+        ride = ride && !ln_group_writes(G.grp.cs_wgs > 0 ? G.grp.cs_out : nullptr);
+        G.grp.tail_wgs = 0;
+        if (ride && tail_take(&G.grp.tail)) {
+            G.grp.tail_wgs = G.grp.tail.first[G.grp.tail.ln.count + G.grp.tail.n_scatter];
+        }
+        hipLaunchKernelGGL((sgemm_group_wgrad<kSmallTilePrefetch>), dim3(G.grp.cs_wgs + G.grp.tail_wgs + G.grp.first[G.count]), dim3(256), 0, rt().stream, G.grp);
+        if (G.grp.tail_wgs > 0) { const int r = tail_taken(); if (r != LG_OK) rc = r; }
     }
     for (int i = 0; i < G.count; ++i)
-        if (G.grp.p[i].W) { const int r = lg_free(G.grp.p[i].W); if (r != LG_OK) rc = r; }     // stream-ordered
+        if (G.queued[i].W) { const int r = lg_free(G.queued[i].W); if (r != LG_OK) rc = r; }     // stream-ordered
     G.count = 0;
     G.tiles = 0;
     G.grp.cs_wgs = 0;
@@ -371,7 +423,7 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
     if (akc || bkc || !va || !vb || batch != 1 || tiles > kGroupTiles || g.relu_a || g.relu_b) return false;
     bool clash = false;
     for (int i = 0; i < G.count; ++i)
-        clash = clash || G.grp.p[i].C == g.C || (g.rowsum && G.grp.p[i].rowsum == g.rowsum);
+        clash = clash || G.queued[i].C == g.C || (g.rowsum && G.queued[i].rowsum == g.rowsum);
     if (ln_group_writes(g.C) || ln_group_writes(g.rowsum)) {
         // an embedding scatter / LayerNorm gradient queued EARLIER writes the same buffer: everything queued leaves now, in call order
         rc = gemm_group_flush_pending();
@@ -382,9 +434,7 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
     }
     g.tickets = rt().gemm_tickets + G.tiles;            // disjoint tickets: the products fold their K-slices side by side
     G.tiles += tiles;
-    G.grp.p[G.count] = g;
-    if (G.count == 0) G.grp.first[0] = 0;
-    G.grp.first[G.count + 1] = G.grp.first[G.count] + g.nwg;
+    G.queued[G.count] = g;
     G.count += 1;
     return true;
 }
@@ -777,7 +827,7 @@ extern "C" int lg_gemm_group_colsum_f32(const float* in, int64_t ld, int64_t row
     const int64_t wgs = (cols + 63) / 64;
     if (G.active == 1 && G.grp.cs_wgs == 0 && rows > 0 && wgs <= 65536 && !lg::pair_state().active) {
         for (int i = 0; i < G.count; ++i)                    // never next to a queued product that writes the same buffer
-            if (G.grp.p[i].rowsum == out || G.grp.p[i].C == out) { const int rc = lg::group_flush(); if (rc != LG_OK) return rc; break; }
+            if (G.queued[i].rowsum == out || G.queued[i].C == out) { const int rc = lg::group_flush(); if (rc != LG_OK) return rc; break; }
         G.grp.cs_in = in; G.grp.cs_out = out;
         G.grp.cs_rows = rows; G.grp.cs_cols = cols; G.grp.cs_ld = ld;
         G.grp.cs_accumulate = accumulate;

@@ -81,6 +81,11 @@ class BertSelfAttention(nn.Module):
 
     def forward(self, hidden, attention_mask=None):
         b, s, _ = hidden.shape
+        if attention_mask is None and hasattr(hidden, "self_attention") and hidden.self_attention_supported(self.query.weight, self.h):
+            # the backend's one-node form of this whole method: one launch for the three projections, one for the attention
+            context = hidden.self_attention(self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                            self.value.weight, self.value.bias, heads=self.h, scale=math.sqrt(self.d) ** -1)
+            return context, context.attention_probs
         q, k, v = self.query(hidden), self.key(hidden), self.value(hidden)
         if attention_mask is None and hasattr(q, "attention") and q.attention_supported(self.h):
             # the backend's one-launch form of everything below (scores, scaling, softmax, context), forward and backward

@@ -235,6 +235,21 @@ int lg_gemm_act_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                     const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                     const float* bias, int act, float* aux, int64_t ldaux);
 
+/* Three Linear layers on ONE input in one launch: C[i] = op(A) @ op(B[i]) + bias[i], i < 3, all of one shape - the query / key /
+ * value projections of a transformer layer (reference examples/bert.py:78-80: three nn.Linear calls, each a kernels.dot and a
+ * bias add).  The three weights stay where they are (separately allocated parameters; their addresses travel as offsets from
+ * B[0]); the three results may be column blocks of one buffer (ldc = its row pitch).  bias may be NULL (no bias at all). */
+int lg_gemm_multi3_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                       const float* const* B, int64_t ldb, float* const* C, int64_t ldc, const float* const* bias);
+
+/* One product whose K dimension runs through three separately allocated right-hand operands of seg_k k-values each:
+ * C (+)= op(A)[M, 3 * seg_k] @ [op(B[0]); op(B[1]); op(B[2])] (+ addend) - the input gradient of the three projections above,
+ * dx = [dq | dk | dv] @ [Wq; Wk; Wv], which the tape forms as three kernels.dot calls and two additions (dot.backward,
+ * cpu/ops.py:116; add_grad, tensor.py:111-118).  seg_k a multiple of 64; the sum runs in K order like one long product. */
+int lg_gemm_kseg3_f32(int transA, int transB, int64_t M, int64_t N, int64_t seg_k, const float* A, int64_t lda,
+                      const float* const* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
+                      const float* addend, int64_t ldadd);
+
 /* lg_gemm_f32 over a TWO-level batch: matrix (o, i) of operand X starts at X + o*strideX_outer + i*strideX_inner.
  * One launch for attention-shaped products whose (batch, head) dims do not collapse into one stride after the head
  * split `reshape(b, s, h, d).transpose(0, 2, 1, 3)` (examples/bert.py:70-95; the reference's kernel is launched per

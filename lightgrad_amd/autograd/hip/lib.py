@@ -86,6 +86,9 @@ PROTOTYPES = {
                                    c_void_p, c_void_p, c_int64]),
     "lg_gemm_act_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                c_void_p, c_int, c_void_p, c_int64]),
+    "lg_gemm_multi3_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "lg_gemm_kseg3_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                 c_void_p, c_int64]),
     "lg_gemm_fused_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
     "lg_gemm_batched2_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,

@@ -1706,6 +1706,99 @@ class attention(Function):
 HipTensor.attention_supported = attention_supported
 
 
+def self_attention_supported(x, wq, heads):
+    """does `x.self_attention(wq, bq, wk, bk, wv, bv, heads, scale)` exist for these shapes?  (b, s, hidden) input, three
+    (width, hidden) weights with width = heads * d, d = 32 or 64, width a multiple of 64, s = 32 .. 128 in 32s"""
+    return (len(x._shape) == 3 and x._dtype == _F32 and len(wq._shape) == 2 and wq._shape[1] == x._shape[2] and wq._shape[0] % heads == 0
+            and wq._shape[0] % 64 == 0 and x._shape[2] % 4 == 0 and x.numel() > 0
+            and bool(_l.lib().lg_attention_supported(x._shape[1], wq._shape[0] // heads)))
+
+
+def _ptr3(a, b, c):
+    return (ctypes.c_void_p * 3)(a, b, c)
+
+
+@HipTensor.register_op()
+class self_attention(Function):
+    """ the query / key / value projections and the attention over them as ONE tape node (reference examples/bert.py:78-88:
+    three nn.Linear, scores, scaling, softmax, context): the three projections are one launch (lg_gemm_multi3_f32 - the weights
+    stay the separately allocated parameters they are) into one (b, s, 3 * width) buffer that the attention kernel reads in
+    place; backward: the attention kernel writes dq | dk | dv into one buffer of that shape, the input gradient is ONE product
+    whose K runs through the three weights (lg_gemm_kseg3_f32, added to a gradient the input already holds in its epilogue),
+    the weight / bias gradients take the routes of `linear`.  `.attention_probs` as for `attention`. """
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, heads=1, scale=1.0):
+        _require_f32(x, wq, bq, wk, bk, wv, bv)
+        assert self_attention_supported(x, wq, heads) and wq._shape == wk._shape == wv._shape and bq._shape == bk._shape == bv._shape == (wq._shape[0],), \
+            "self_attention: unsupported shapes %s with weights %s / %s / %s and %d heads" % (x._shape, wq._shape, wk._shape, wv._shape, heads)
+        b, s, hidden = x._shape
+        width = wq._shape[0]
+        x = x.contiguous()
+        ws, bs = [w.contiguous() for w in (wq, wk, wv)], [t.contiguous() for t in (bq, bk, bv)]
+        qkv = HipTensor.empty((b, s, 3 * width), requires_grad=False)
+        base = qkv.ptr
+        _l.check(_l.lib().lg_gemm_multi3_f32(0, 1, b * s, width, hidden, x.ptr, hidden, _ptr3(*(w.ptr for w in ws)), hidden,
+                                             _ptr3(base, base + 4 * width, base + 8 * width), 3 * width, _ptr3(*(t.ptr for t in bs))))
+        out = HipTensor.empty((b, s, width))
+        probs = HipTensor.empty((b, heads, s, s), requires_grad=False)
+        ld, sb = 3 * width, s * 3 * width
+        _l.check(_l.lib().lg_attention_fwd_f32(base, ld, sb, base + 4 * width, ld, sb, base + 8 * width, ld, sb, out.ptr, width, s * width,
+                                               probs.ptr, b, heads, s, width // heads, float(scale)))
+        ctx.save_for_backward(x, qkv, probs, heads, float(scale))
+        out.attention_probs = probs
+        return out
+
+    def backward(ctx, out_grad):
+        x, qkv, probs, heads, scale = ctx.get_saved_tensors()
+        x_in = ctx._parents[0]
+        params = ctx._parents[1:7]
+        b, s, hidden = x._shape
+        width = qkv._shape[2] // 3
+        g, ldg, sbg = _token_rows(out_grad)
+        dqkv = HipTensor.empty((b, s, 3 * width), requires_grad=False)
+        base, dbase = qkv.ptr, dqkv.ptr
+        ld, sb = 3 * width, s * 3 * width
+        _l.check(_l.lib().lg_attention_bwd_f32(base, ld, sb, base + 4 * width, ld, sb, base + 8 * width, ld, sb, g.ptr, ldg, sbg, probs.ptr,
+                                               dbase, ld, sb, dbase + 4 * width, ld, sb, dbase + 8 * width, ld, sb,
+                                               b, heads, s, width // heads, scale))
+        x2 = x.reshape(-1, hidden)
+        grads = []
+        for i in range(3):
+            weight, bias = params[2 * i], params[2 * i + 1]
+            gi = HipTensor(dqkv.data, (b * s, width), (3 * width, 1), dqkv._offset + i * width, _F32, requires_grad=False)
+            want_db = bias.requires_grad
+            acc_w = weight._grad_accumulator() if weight.requires_grad else None
+            acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
+            acc_b = bias._grad_accumulator() if want_db else None
+            acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+            if acc_w is not None and (not want_db or acc_b is not None) and GradGroup.usable_for(weight, bias):
+                with GradGroup.issue(reads=(gi, x2), writes=(acc_w, acc_b)):
+                    grads += list(linear._weight_products(x2, weight, bias, want_db, gi, acc_w, acc_b))
+            else:
+                grads += list(linear._weight_products(x2, weight, bias, want_db, gi, acc_w, acc_b))
+        dx = None
+        if x_in.requires_grad:
+            ws = [params[0].contiguous(), params[2].contiguous(), params[4].contiguous()]
+            wptrs = _ptr3(*(w.ptr for w in ws))
+            have = x_in._grad if (x_in._ctx is not None and x_in._view_of_leaf is None) else None
+            if (have is not None and have.__class__ is HipTensor and have._shape == x_in._shape and have._dtype == _F32 and have.is_contiguous()):
+                # the input already holds a contribution (the residual branch): added in this product's epilogue
+                if x_in._grad_shared:
+                    new = HipTensor.empty(x_in._shape, requires_grad=False)
+                    _l.check(_l.lib().lg_gemm_kseg3_f32(0, 0, b * s, hidden, width, dbase, 3 * width, wptrs, hidden, new.ptr, hidden, 0,
+                                                        have.ptr, hidden))
+                    x_in._grad, x_in._grad_shared = new, False
+                else:
+                    flush_lazy_readers(have)
+                    _l.check(_l.lib().lg_gemm_kseg3_f32(0, 0, b * s, hidden, width, dbase, 3 * width, wptrs, hidden, have.ptr, hidden, 1, None, 0))
+            else:
+                dx = HipTensor.empty(x_in._shape, requires_grad=False)
+                _l.check(_l.lib().lg_gemm_kseg3_f32(0, 0, b * s, hidden, width, dbase, 3 * width, wptrs, hidden, dx.ptr, hidden, 0, None, 0))
+        return (dx,) + tuple(grads)
+
+
+HipTensor.self_attention_supported = self_attention_supported
+
+
 @HipTensor.register_op()
 class layer_norm(Function):
     """ nn.LayerNorm over the last axis in one kernel (composite: nn.py:109-124); backward dx fused,

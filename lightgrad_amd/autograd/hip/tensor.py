@@ -67,7 +67,7 @@ class GradGroup(object):
     Hazards: the queued launches read activations / gradients later - `keep` holds them alive, and an in-place writer into
     their storage or into the gradient buffers (flush_lazy_readers is the hook of every in-place writer) flushes the queue
     first; the library itself flushes before anything that exposes results to the host or to another graph."""
-    MIN_NODES = 24          # (tiny-BERT with fused attention: 41 nodes; the MLP of the headline: 9)
+    MIN_NODES = 14          # (tiny-BERT with its fused blocks: about 20 nodes; the MLP of the headline: 6)
     enabled = os.environ.get("LIGHTGRAD_GRAD_GROUP", "1") != "0"
     depth = 0             # nested backward passes (WrapperFunction replays its inner tape with Gradients.backward)
     active = False

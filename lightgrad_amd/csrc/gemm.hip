@@ -100,6 +100,14 @@ struct GemmArgs {
     // the argument block of the group launch has no room for a pitch of its own).
     int     act;
     float*  aux;
+    // three products of one shape that share op(A), in ONE launch (lg_gemm_multi3_f32; batch = 3): product b reads
+    // B + boff[b], adds bias + biasoff[b] and writes C + coff[b] - three separately allocated weights, no packing copy
+    int     multi;
+    int64_t boff[3], coff[3], biasoff[3];
+    // one product whose K runs through three separately allocated B operands of seg_k k-values each (lg_gemm_kseg3_f32:
+    // dx = [g0 | g1 | g2] @ [W0; W1; W2]): every seg_steps K-steps the running B pointer jumps to the next operand
+    int     seg_k, seg_steps;
+    int64_t seg_jump[2];
 #ifdef LG_GEMM_TIMELINE
     // experiments build only (make timeline; tools/gemm_timeline.py): 8 timestamps of the 100 MHz wall clock per workgroup
     unsigned long long* tl;
@@ -420,7 +428,7 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
     rc = LG_OK;
     if (G.active != 1 || pair_state().active) return false;
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n;
-    if (akc || bkc || !va || !vb || batch != 1 || tiles > kGroupTiles || g.relu_a || g.relu_b) return false;
+    if (akc || bkc || !va || !vb || batch != 1 || tiles > kGroupTiles || g.relu_a || g.relu_b || g.multi || g.seg_k) return false;
     bool clash = false;
     for (int i = 0; i < G.count; ++i)
         clash = clash || G.queued[i].C == g.C || (g.rowsum && G.queued[i].rowsum == g.rowsum);
@@ -497,6 +505,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         int s0 = 0, s1 = 0;
         if (sscanf(pair_slices_env, "%d,%d", &s0, &s1) == 2) { const int v = pair_state().count == 0 ? s0 : s1; if (v >= 1) slices = v; }
     }
+    if (g.seg_k) { slices = 1; g.seg_steps = g.seg_k / (BK * KG); }      // (seg_k is a multiple of 64 = the widest K-step)
     g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;
     slices = (g.K + g.k_per_slice - 1) / g.k_per_slice;
     g.k_slices = int(slices);
@@ -560,7 +569,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                      int64_t batch, int accumulate, const float* bias, float* rowsum = nullptr, int rowsum_accumulate = 0,
                      int64_t batch_inner = 1, int64_t strideA2 = 0, int64_t strideB2 = 0, int64_t strideC2 = 0,
                      int relu_a = 0, int relu_b = 0, const float* addend = nullptr, int64_t ldadd = 0,
-                     int act = 0, float* aux = nullptr, int64_t ldaux = 0) {
+                     int act = 0, float* aux = nullptr, int64_t ldaux = 0, const GemmArgs* extras = nullptr) {
     LG_REQUIRE_INIT();
     LG_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, "lg_gemm_f32: negative extent (M=%lld N=%lld K=%lld batch=%lld)",
            (long long)M, (long long)N, (long long)K, (long long)batch);
@@ -614,7 +623,13 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     if (act) g.ldadd = ldaux;
     LG_ARG(act == 0 || (batch == 1 && rowsum == nullptr && addend == nullptr && aux != nullptr && ldaux >= N && K > 0 && (act == 1 || act == 2)),
            "lg_gemm_act_f32: one matrix product with K > 0, act 1 or 2, aux [M, N] with ldaux >= N");
-    const bool fused_extras = rowsum != nullptr || relu_a || relu_b || act != 0;     // not compiled into the 256x256 tile
+    if (extras) {               // (lg_gemm_multi3_f32 / lg_gemm_kseg3_f32 have checked their own arguments)
+        g.multi = extras->multi;
+        for (int i = 0; i < 3; ++i) { g.boff[i] = extras->boff[i]; g.coff[i] = extras->coff[i]; g.biasoff[i] = extras->biasoff[i]; }
+        g.seg_k = extras->seg_k;
+        g.seg_jump[0] = extras->seg_jump[0]; g.seg_jump[1] = extras->seg_jump[1];
+    }
+    const bool fused_extras = rowsum != nullptr || relu_a || relu_b || act != 0 || g.multi || g.seg_k;     // not compiled into the 256x256 tile
     LG_ARG(!(relu_a || relu_b) || batch == 1, "lg_gemm_fused_f32: one matrix product");
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
@@ -818,6 +833,39 @@ extern "C" int lg_gemm_act_f32(int transA, int transB, int64_t M, int64_t N, int
     LG_ARG(act == LG_ACT_GELU || bias == nullptr, "lg_gemm_act_f32: the backward form takes no bias");
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, 0, bias, nullptr, 0, 1, 0, 0, 0, 0, 0, nullptr, 0,
                      act, aux, ldaux);
+}
+
+extern "C" int lg_gemm_multi3_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                                  const float* const* B, int64_t ldb, float* const* C, int64_t ldc, const float* const* bias) {
+    LG_ARG(B && C && B[0] && B[1] && B[2] && C[0] && C[1] && C[2], "lg_gemm_multi3_f32: NULL operand");
+    LG_ARG(bias == nullptr || (bias[0] && bias[1] && bias[2]), "lg_gemm_multi3_f32: three bias rows or none");
+    LG_ARG(!lg::pair_state().active, "lg_gemm_multi3_f32: not inside a pair bracket");
+    GemmArgs x{};
+    x.multi = 1;
+    for (int i = 0; i < 3; ++i) {
+        x.boff[i] = B[i] - B[0];
+        x.coff[i] = C[i] - C[0];
+        x.biasoff[i] = bias ? bias[i] - bias[0] : 0;
+    }
+    return gemm_impl(transA, transB, M, N, K, A, lda, 0, B[0], ldb, 0, C[0], ldc, 0, 3, 0, bias ? bias[0] : nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0,
+                     nullptr, 0, 0, nullptr, 0, &x);
+}
+
+extern "C" int lg_gemm_kseg3_f32(int transA, int transB, int64_t M, int64_t N, int64_t seg_k, const float* A, int64_t lda,
+                                 const float* const* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
+                                 const float* addend, int64_t ldadd) {
+    LG_ARG(B && B[0] && B[1] && B[2], "lg_gemm_kseg3_f32: NULL operand");
+    LG_ARG(seg_k >= 64 && seg_k % 64 == 0, "lg_gemm_kseg3_f32: seg_k = %lld must be a positive multiple of 64", (long long)seg_k);
+    LG_ARG(!(accumulate && addend), "lg_gemm_kseg3_f32: accumulate or addend, not both");
+    LG_ARG(!lg::pair_state().active, "lg_gemm_kseg3_f32: not inside a pair bracket");
+    GemmArgs x{};
+    x.seg_k = int(seg_k);
+    // at the end of operand i the running pointer stands at B[i] + seg_k * step, step = 1 along a K-contiguous B, ldb otherwise
+    const int64_t span = seg_k * (transB ? 1 : ldb);
+    x.seg_jump[0] = (B[1] - B[0]) - span;
+    x.seg_jump[1] = (B[2] - B[1]) - span;
+    return gemm_impl(transA, transB, M, N, 3 * seg_k, A, lda, 0, B[0], ldb, 0, C, ldc, 0, 1, accumulate, nullptr, nullptr, 0, 1, 0, 0, 0, 0, 0,
+                     addend, ldadd, 0, nullptr, 0, &x);
 }
 
 extern "C" int lg_gemm_group_colsum_f32(const float* in, int64_t ld, int64_t rows, int64_t cols, float* out, int accumulate) {

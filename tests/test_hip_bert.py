@@ -259,6 +259,50 @@ def test_embedding_gather_and_scatter_add(hip):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=str((n_ids, hot)))
 
 
+@pytest.mark.parametrize("b,s,hidden,heads,d", [(8, 128, 128, 2, 64), (2, 64, 96, 2, 32), (1, 32, 40, 3, 64)])
+def test_self_attention_node(hip, b, s, hidden, heads, d):
+    """projections + attention as one node (one launch for q / k / v, one for the attention; backward: one attention launch, ONE
+    input-gradient product through the three weights): context, probabilities, the input gradient - also on top of a
+    contribution the input already holds (a residual branch) - and the six parameter gradients against a float64 run of the
+    composite, no further from it than twice the three-Linear + composite-attention form on the same backend"""
+    rng = np.random.RandomState(10)
+    width = heads * d
+    scale = float(np.sqrt(d)) ** -1
+    x = rng.uniform(-1, 1, (b, s, hidden)).astype(np.float32)
+    params = []
+    for _ in range(3):
+        params += [rng.uniform(-0.2, 0.2, (width, hidden)).astype(np.float32), rng.uniform(-0.2, 0.2, (width,)).astype(np.float32)]
+    w = rng.uniform(-1, 1, (b, s, width)).astype(np.float32)
+    r = rng.uniform(-1, 1, (b, s, hidden)).astype(np.float32)
+
+    def run(T, f64, fused):
+        cast = (lambda a: a.astype(np.float64)) if f64 else (lambda a: a)
+        leaf = T.from_numpy(cast(x))
+        tx = leaf * 1.0                                            # an intermediate: its gradient may be built in an epilogue
+        ps = [T.from_numpy(cast(p)) for p in params]
+        if fused:
+            assert tx.self_attention_supported(ps[0], heads)
+            out = tx.self_attention(*ps, heads=heads, scale=scale)
+            probs = out.attention_probs
+        else:
+            q, k, v = (tx @ ps[2 * i].transpose(1, 0) + ps[2 * i + 1] for i in range(3))
+            out, probs = composite_attention(q, k, v, heads, scale)
+        # a residual branch first: the input holds a gradient when the node's backward runs
+        ((tx * T.from_numpy(cast(r), requires_grad=False)).sum() + (out * T.from_numpy(cast(w), requires_grad=False)).sum()).backward()
+        return [out.numpy(), probs.numpy(), leaf.grad.numpy()] + [p.grad.numpy() for p in ps]
+    fused, plain = run(hip, False, True), run(hip, False, False)
+    with float64_tape():
+        ref = run(CpuTensor, True, False)
+    names = ["context", "probs", "dx", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv"]
+    for name, f, p_, want in zip(names, fused, plain, ref):
+        if name == "dbk":                                          # mathematically zero: rounding noise on every path
+            assert np.abs(f).max() < 1e-4 * np.abs(ref[4]).max() + 1e-6
+            continue
+        e_f, e_p = rel_frobenius(f, want), rel_frobenius(p_, want)
+        assert e_f <= 1e-5, (name, e_f, e_p)
+        assert e_f <= 2 * e_p + 3e-7, (name, e_f, e_p)
+
+
 @pytest.mark.parametrize("dtype", [np.int32, np.int64])
 def test_embedding_sum_is_the_three_lookups_and_two_adds(hip, dtype):
     """word + position + token-type embeddings in one pass: the bits of the composite line of examples/bert.py, values and

@@ -11,10 +11,15 @@
 //
 // Work split.  Forward: one workgroup per (batch, head, block of 32 queries).  Backward: two roles, one workgroup each per
 // (batch, head, block of 32): the QUERY role makes dQ of its 32 queries, the KEY role dK and dV of its 32 keys.  The key role
-// needs dS[:, block] for ALL queries and therefore the softmax shift of every row, a sum over the whole row of dP: it
-// recomputes dP for all queries (S x S x D, 128 MFMAs per wave at S = 128) rather than wait for the query-role workgroups -
-// no hand-off inside the launch, and both roles run the same code on the same values, so their dS agree bit for bit.
-// The shift is formed in double exactly like the separate softmax backward (rowwise.hip: softmax_bwd explains why).
+// needs dS[:, block] for ALL queries: dP only for its own keys (32 MFMAs per wave) but the softmax shift of every row, a sum
+// over the whole row of dP.  The query-role workgroups form those sums anyway and hand them over inside the launch: each
+// publishes its 32 shifts (write-through doubles) and raises a counter of its (batch, head) pair; a key-role workgroup waits
+// for the counter to reach S / 32.  The query-role workgroups fill the front of the grid, so whoever waits, waits for
+// workgroups that are already running and wait for nothing; the wait is bounded (2 s, then the device status flag).  The
+// first version recomputed dP for all queries in the key role instead (128 MFMAs per wave and a row pass over S rows:
+// 14.8 us for the role against 11.6 us with the hand-off, tools/attn_timeline.py).  Both roles run the same MFMA sequence on the
+// same operands, so their dP - and dS - agree bit for bit.  The shift is formed in double exactly like the separate softmax
+// backward (rowwise.hip: softmax_bwd explains why).
 //
 // MFMA operands come from LDS.  v_mfma_f32_32x32x2f32 takes one float per lane: lane (r, h) = (lane & 31, lane >> 5) holds
 // A[r][k + h] and B[k + h][r].  Any order of the k values will do as long as A and B agree, so a wave walks K in groups of
@@ -165,8 +170,11 @@ struct AttnBwdArgs {
     const float* p;                  // probabilities saved by the forward
     float *dq, *dk, *dv;
     int64_t lddq, sbdq, lddk, sbdk, lddv, sbdv;
-    int S, heads;
+    int S, heads, batch;
     float scale;
+    double* shift;                   // [batch, heads, S]: the softmax shift of every query row, query role -> key role
+    int*    flags;                   // [batch * heads][2]: rows published / key-role workgroups served; zero between launches
+    int*    status;                  // device status flag (a wait that gives up raises it)
 };
 
 // The probabilities a thread needs for its rows: row = (tid >> 3) + 32 * pass, float4 columns (tid & 7) + 8 * i.  Fetched into
@@ -188,59 +196,43 @@ __device__ __forceinline__ void load_probs(ProbRows<PASSES>& pr, const float* y,
     }
 }
 
-// dS = float(double(y) * (double(g) - shift)) * scale, shift = sum(g * y) / sum(y) over the row in double, for `rows` rows of
-// dP held in LDS (pitch pp) against their probabilities y (load_probs).  8 threads per row.
-//   WHOLE: dS replaces dP in place.   !WHOLE: only columns [c0, c0 + 32) are kept - dS into dsc, y into pc (pitch pc_pitch).
-template <bool WHOLE, int PASSES>
-__device__ __forceinline__ void softmax_bwd_rows(float* dp, int pp, const ProbRows<PASSES>& pr, int S, int rows, float scale,
-                                                 int c0, float* dsc, float* pc, int pc_pitch) {
-    const int sub = threadIdx.x & 7;
+// dS = float(double(y) * (double(g) - shift)) * scale, shift = sum(g * y) / sum(y) over the row in double, in place, for 32 rows of
+// dP held in LDS (pitch pp) against their probabilities y (load_probs); 8 threads per row.  The shift of every row is also
+// stored to `shift_out` (write-through: workgroups on other XCDs read it).
+__device__ __forceinline__ void softmax_bwd_rows(float* dp, int pp, const ProbRows<1>& pr, int S, float scale, double* shift_out) {
+    const int sub = threadIdx.x & 7, row = threadIdx.x >> 3;
+    float* gr = dp + row * pp;
+    af32x4 g4[4];
+    double dot = 0.0, norm = 0.0;
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int row = (threadIdx.x >> 3) + 32 * p;
-        if (row < rows) {                                        // (all 64 lanes of a wave agree: rows is a multiple of 32)
-            float* gr = dp + row * pp;
-            af32x4 g4[4];
-            double dot = 0.0, norm = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub * 4 + 32 * i;
+        if (c < S) {
+            g4[i] = *reinterpret_cast<const af32x4*>(gr + c);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = sub * 4 + 32 * i;
-                if (c < S) {
-                    g4[i] = *reinterpret_cast<const af32x4*>(gr + c);
+            for (int e = 0; e < 4; ++e) { const double yc = double(pr.y[0][i][e]); dot += double(g4[i][e]) * yc; norm += yc; }
+        }
+    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const double yc = double(pr.y[p][i][e]); dot += double(g4[i][e]) * yc; norm += yc; }
-                }
-            }
+    for (int off = 1; off < 8; off <<= 1) { dot += __shfl_xor(dot, off, 64); norm += __shfl_xor(norm, off, 64); }
+    const double shift = dot / norm;
+    if (sub == 0) __hip_atomic_store(shift_out + row, shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int off = 1; off < 8; off <<= 1) { dot += __shfl_xor(dot, off, 64); norm += __shfl_xor(norm, off, 64); }
-            const double shift = dot / norm;
+    for (int i = 0; i < 4; ++i) {
+        const int c = sub * 4 + 32 * i;
+        if (c < S) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = sub * 4 + 32 * i;
-                if (c < S) {
-                    if constexpr (WHOLE) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) g4[i][e] = float(double(pr.y[p][i][e]) * (double(g4[i][e]) - shift)) * scale;
-                        *reinterpret_cast<af32x4*>(gr + c) = g4[i];
-                    } else if (c >= c0 && c < c0 + 32) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            dsc[row * pc_pitch + (c - c0) + e] = float(double(pr.y[p][i][e]) * (double(g4[i][e]) - shift)) * scale;
-                            pc[row * pc_pitch + (c - c0) + e] = pr.y[p][i][e];
-                        }
-                    }
-                }
-            }
+            for (int e = 0; e < 4; ++e) g4[i][e] = float(double(pr.y[0][i][e]) * (double(g4[i][e]) - shift)) * scale;
+            *reinterpret_cast<af32x4*>(gr + c) = g4[i];
         }
     }
 }
 
-// floats of LDS: the key role is the larger one
+// floats of LDS: the larger of the two roles
 template <int D>
 constexpr int attn_bwd_lds_floats(int S) {
     const int query = 32 * (D + 4) + S * (D + 4) + S * (D + 8) + 32 * (S + 4) + 3 * 1024;
-    const int big = S * (S + 4) > S * (D + 8) ? S * (S + 4) : S * (D + 8);
-    const int key = S * (D + 8) + big + 2 * S * 40 + 2048;
+    const int key = 2 * S * (D + 8) + 32 * (D + 4) + 2 * S * 40 + 2048;
     return query > key ? query : key;
 }
 
@@ -249,15 +241,21 @@ __global__ void __launch_bounds__(256) attn_bwd(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int S = a.S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int blk = blockIdx.x >> 1, role = blockIdx.x & 1, head = blockIdx.y, b = blockIdx.z;
-    const int j0 = blk * 32;
-    const float* pg = a.p + (int64_t(b) * a.heads + head) * S * S;
+    // the query-role workgroups of the whole grid are dispatched before any key-role one (role in the slowest grid index): a
+    // key-role workgroup that waits, waits for workgroups that are already running and wait for nothing
+    const int role = int(blockIdx.z) >= a.batch ? 1 : 0;
+    const int blk = blockIdx.x, head = blockIdx.y, b = int(blockIdx.z) - role * a.batch;
+    const int j0 = blk * 32, nblk = S / 32;
+    const int bh = b * a.heads + head;
+    const float* pg = a.p + int64_t(bh) * S * S;
+    double* shifts = a.shift + int64_t(bh) * S;
+    int* flags = a.flags + 2 * bh;
     constexpr int NT = D / 32;
     constexpr int NB = 32 * (D / 4) / 256 > 0 ? 32 * (D / 4) / 256 : 1, NA = 128 * (D / 4) / 256;       // float4 per thread: 32 rows / all rows
 
     LG_ATL(0);
     if (role == 0) {
-        // ---- query role: dQ of queries [j0, j0 + 32) ----------------------------------------------------------
+        // ---- query role: dQ of queries [j0, j0 + 32), and the shift of their rows for the key role ------------------
         constexpr int PG = D + 4, PVK = D + 4, PK = D + 8;
         const int PP = S + 4;
         float* Gs = lds;                 // dO rows of the block          32 x PG
@@ -286,8 +284,10 @@ __global__ void __launch_bounds__(256) attn_bwd(AttnBwdArgs a) {
         }
         __syncthreads();
         LG_ATL(2);
-        softmax_bwd_rows<true, 1>(Ss, PP, probs, S, 32, a.scale, 0, nullptr, nullptr, 0);
+        softmax_bwd_rows(Ss, PP, probs, S, a.scale, shifts + j0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the shifts have left this CU
         __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // 32 more rows are published
         LG_ATL(3);
         constexpr int KP = 4 / NT;
         const int n = wave % NT, kp = wave / NT;
@@ -315,57 +315,75 @@ __global__ void __launch_bounds__(256) attn_bwd(AttnBwdArgs a) {
     }
 
     // ---- key role: dK and dV of keys [j0, j0 + 32) --------------------------------------------------------------
+    // dS[:, block] = P[:, block] o (dP[:, block] - shift) * scale needs dP only for the block's own keys (32 MFMAs per wave, query
+    // rows [32 w, 32 w + 32) each) - and the shift of EVERY row, a sum over the whole row of dP that the query-role workgroups of
+    // this (batch, head) have formed: they publish it, a counter says how many of them have.  The values of dP agree bit for bit
+    // between the roles (the same MFMA sequence over the same operands), so dS does too.
     constexpr int PG = D + 8;            // dO: K-contiguous A of dP (two-way conflicts there) and N-contiguous B of dV
     constexpr int PVK = D + 4, PQN = D + 8, PC = 40;
-    const int PP = S + 4;
-    const int big = S * PP > S * PQN ? S * PP : S * PQN;
     float* Gs = lds;                     // dO, all queries               S x PG
-    float* R1 = Gs + S * PG;             // V (S x PVK), then dP (S x PP), then Q (S x PQN)
-    float* Pc = R1 + big;                // P[:, block]                   S x PC
+    float* Qs = Gs + S * PG;             // Q, N-contiguous B of dK       S x PQN
+    float* Vj = Qs + S * PQN;            // V rows of the block           32 x PVK
+    float* Pc = Vj + 32 * PVK;           // P[:, block]                   S x PC
     float* Dc = Pc + S * PC;             // dS[:, block]                  S x PC
     float* Red = Dc + S * PC;
-    af32x4 rq[NA];                       // Q waits in registers until dP has left R1
     {
-        af32x4 rg[NA], rv[NA];
+        af32x4 rg[NA], rq[NA], rv[NB];
         load_rows<D, NA>(rg, a.g + int64_t(b) * a.sbg + head * D, a.ldg, S);
-        load_rows<D, NA>(rv, a.v + int64_t(b) * a.sbv + head * D, a.ldv, S);
         load_rows<D, NA>(rq, a.q + int64_t(b) * a.sbq + head * D, a.ldq, S);
+        load_rows<D, NB>(rv, a.v + int64_t(b) * a.sbv + int64_t(j0) * a.ldv + head * D, a.ldv, 32);
         store_rows<D, NA>(rg, Gs, PG, S);
-        store_rows<D, NA>(rv, R1, PVK, S);
+        store_rows<D, NA>(rq, Qs, PQN, S);
+        store_rows<D, NB>(rv, Vj, PVK, 32);
     }
-    ProbRows<4> probs;
-    load_probs<4>(probs, pg, S, S);
+    const bool active = 32 * wave < S;
+    // the probabilities that meet this wave's block of dP: element e of the accumulator is (row 32 w + acc_row(e, h), key j0 + r)
+    float y[16];
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = pg[int64_t(32 * wave + acc_row(e, h)) * S + j0 + r];
+    }
     __syncthreads();
     LG_ATL(1);
-    // dP for ALL queries: wave w takes query rows [32 w, 32 w + 32) against every key block
-    af32x16 dp[4];
-    const bool active = 32 * wave < S;
-    if (active) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            dp[t] = zero16();
-            if (32 * t < S) wave_mma<true, true>(dp[t], Gs + 32 * wave * PG, PG, R1 + 32 * t * PVK, PVK, D, r, h);
-        }
-    }
-    __syncthreads();                     // every wave is done with V
+    af32x16 dp = zero16();
+    if (active) wave_mma<true, true>(dp, Gs + 32 * wave * PG, PG, Vj, PVK, D, r, h);
     LG_ATL(2);
-    if (active) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (32 * t < S) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) R1[(32 * wave + acc_row(e, h)) * PP + 32 * t + r] = dp[t][e];
+    // wait for the shifts of all S rows
+    if (tid == 0) {
+        // (bounded: 2 s of the 100 MHz wall clock, then the device status flag is raised and the launch runs to its end)
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblk) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ull) {
+                __hip_atomic_fetch_or(a.status, LG_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
             }
         }
     }
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     LG_ATL(3);
-    softmax_bwd_rows<false, 4>(R1, PP, probs, S, S, a.scale, j0, Dc, Pc, PC);
-    __syncthreads();                     // dP is no longer needed: Q takes its place
-    LG_ATL(4);
-    store_rows<D, NA>(rq, R1, PQN, S);
+    if (active) {
+        double sh[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sh[e] = __hip_atomic_load(shifts + 32 * wave + acc_row(e, h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * wave + acc_row(e, h);
+            Dc[row * PC + r] = float(double(y[e]) * (double(dp[e]) - sh[e])) * a.scale;
+            Pc[row * PC + r] = y[e];
+        }
+    }
     __syncthreads();
-    LG_ATL(5);
+    // every wave has read its shifts: this workgroup is served; the last one of the (batch, head) pair clears the counters
+    if (tid == 0) {
+        const int served = __hip_atomic_fetch_add(flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (served == nblk - 1) {
+            __hip_atomic_store(flags, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    LG_ATL(4);
     // dV = P[:, block]^T @ dO and dK = dS[:, block]^T @ Q: 2 * NT output tiles of 32 x 32 over four waves
     constexpr int TILES = 2 * NT, KP = 4 / TILES > 0 ? 4 / TILES : 1;
     const int tile = wave % TILES, kp = wave / TILES;
@@ -373,9 +391,9 @@ __global__ void __launch_bounds__(256) attn_bwd(AttnBwdArgs a) {
     const int n = tile % NT;
     const int kspan = S / KP;
     af32x16 acc = zero16();
-    if (is_dk) wave_mma<false, false>(acc, Dc + kp * kspan * PC, PC, R1 + kp * kspan * PQN + 32 * n, PQN, kspan, r, h);
+    if (is_dk) wave_mma<false, false>(acc, Dc + kp * kspan * PC, PC, Qs + kp * kspan * PQN + 32 * n, PQN, kspan, r, h);
     else       wave_mma<false, false>(acc, Pc + kp * kspan * PC, PC, Gs + kp * kspan * PG + 32 * n, PG, kspan, r, h);
-    LG_ATL(6);
+    LG_ATL(5);
     if constexpr (KP > 1) {
         if (kp > 0) {
 #pragma unroll
@@ -393,7 +411,7 @@ __global__ void __launch_bounds__(256) attn_bwd(AttnBwdArgs a) {
     const int64_t ldd = is_dk ? a.lddk : a.lddv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) dst[int64_t(acc_row(e, h)) * ldd] = acc[e];
-    LG_ATL(7);
+    LG_ATL(6);
 }
 
 template <class K>
@@ -473,12 +491,21 @@ extern "C" int lg_attention_bwd_f32(const float* q, int64_t ldq, int64_t sbq, co
            "lg_attention_bwd_f32: operands must be 16-byte aligned with pitches that are multiples of 4");
     const int64_t w = heads * D;
     LG_ARG(ldq >= w && ldk >= w && ldv >= w && ldg >= w && lddq >= w && lddk >= w && lddv >= w, "lg_attention_bwd_f32: row pitch below heads * D");
+    LG_ARG(batch * heads <= rt().n_attn_pairs && 2 * batch <= 65535, "lg_attention_bwd_f32: more than %d (batch, head) pairs in one launch",
+           rt().n_attn_pairs);
+    int* flags = rt().attn_flags;
+    double* shift = nullptr;
+    {
+        const int mrc = lg_malloc(reinterpret_cast<void**>(&shift), size_t(batch * heads * S) * sizeof(double));
+        if (mrc != LG_OK) return mrc;
+    }
     AttnBwdArgs a{
 #ifdef LG_GEMM_TIMELINE
         timeline_buffer(int(2 * (S / 32) * heads * batch)),
 #endif
-        q, k, v, g, ldq, sbq, ldk, sbk, ldv, sbv, ldg, sbg, p, dq, dk, dv, lddq, sbdq, lddk, sbdk, lddv, sbdv, int(S), int(heads), scale};
-    const dim3 grid(unsigned(2 * (S / 32)), unsigned(heads), unsigned(batch));
+        q, k, v, g, ldq, sbq, ldk, sbk, ldv, sbv, ldg, sbg, p, dq, dk, dv, lddq, sbdq, lddk, sbdk, lddv, sbdv, int(S), int(heads), int(batch), scale,
+        shift, flags, rt().status_dev};
+    const dim3 grid(unsigned(S / 32), unsigned(heads), unsigned(2 * batch));
     if (D == 64) {
         const size_t bytes = size_t(attn_bwd_lds_floats<64>(int(S))) * 4;
         int rc = allow_lds(&attn_bwd<64>, bytes);
@@ -491,7 +518,7 @@ extern "C" int lg_attention_bwd_f32(const float* q, int64_t ldq, int64_t sbq, co
         hipLaunchKernelGGL(attn_bwd<32>, grid, dim3(256), bytes, rt().stream, a);
     }
     LG_CHECK_LAUNCH();
-    return LG_OK;
+    return lg_free(shift);          // stream-ordered: the block is only reused by later launches
 }
 
 #ifdef LG_GEMM_TIMELINE

@@ -21,6 +21,9 @@ struct Runtime {
     // arrives last at a tile folds the partial products and resets the counter
     int*        gemm_tickets = nullptr;
     int         n_gemm_tickets = 0;
+    // hand-off counters of the fused attention backward (attention.hip): two per (batch, head) pair, zero between launches
+    int*        attn_flags = nullptr;
+    int         n_attn_pairs = 1 << 14;
     // device status flag: one int in pinned, device-mapped host memory.  Kernels that meet an index / label out of
     // range OR a bit into it (system scope); lg_sync / lg_memcpy_d2h read it from the host side after their stream
     // synchronisation and report LG_EINDEX once.
@@ -29,6 +32,7 @@ struct Runtime {
 };
 
 constexpr int LG_STATUS_BAD_INDEX = 1;
+constexpr int LG_STATUS_HANDOFF_TIMEOUT = 4; // a workgroup of attention.hip's backward gave up waiting for its producers
 constexpr int LG_STATUS_P2P_TIMEOUT = 2;     // a wait of the peer-window exchange (p2p.hip) gave up: a peer is gone
 
 // after a stream synchronisation: turn a raised status flag into an error (and clear it)

@@ -75,6 +75,11 @@ int check_device_status(const char* who) {
                   "buckets and parameters of this rank are not to be trusted (device status %d)", who, what, status);
         return LG_ECOMM;
     }
+    if (status & LG_STATUS_HANDOFF_TIMEOUT) {
+        set_error("%s: the attention backward launched earlier gave up waiting for the workgroups it depends on (2 s; device status %d): "
+                  "its gradients are not to be trusted", who, status);
+        return LG_EHIP;
+    }
     set_error("%s: a kernel launched earlier met an index or label outside its axis (device status %d); results of that "
               "launch hold all-ones bytes / NaN where the index was bad", who, status);
     return LG_EINDEX;
@@ -161,6 +166,8 @@ int lg_init(int device) {
     R.n_gemm_tickets = 1 << 16;
     LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.gemm_tickets), size_t(R.n_gemm_tickets) * sizeof(int)));
     LG_HIP(hipMemset(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int)));    // synchronous: ordered before any launch
+    LG_HIP(hipMalloc(reinterpret_cast<void**>(&R.attn_flags), size_t(R.n_attn_pairs) * 2 * sizeof(int)));
+    LG_HIP(hipMemset(R.attn_flags, 0, size_t(R.n_attn_pairs) * 2 * sizeof(int)));
     LG_HIP(hipHostMalloc(reinterpret_cast<void**>(&R.status_host), 64, hipHostMallocMapped));
     R.status_host[0] = 0;
     LG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&R.status_dev), R.status_host, 0));

@@ -45,5 +45,7 @@ for rep in range(3):
     for t in (q, k, v):
         t.zero_grad()
 report("forward", fwd, ["loads -> LDS", "scores (MFMA) -> LDS", "softmax, P -> HBM", "context MFMAs", "partial sums -> LDS", "fold, O -> HBM"])
-report("backward, query role", bwd[0::2], ["loads -> LDS", "dP (MFMA) -> LDS", "dS rows", "dQ MFMAs", "(unused)", "fold, dQ -> HBM"][:6])
-report("backward, key role", bwd[1::2], ["loads -> LDS", "dP, all queries (MFMA)", "dP -> LDS", "dS rows, all queries", "Q -> LDS", "dV / dK MFMAs", "dV / dK -> HBM"])
+half = len(bwd) // 2                       # the query-role workgroups fill the first half of the grid
+report("backward, query role", bwd[:half], ["loads -> LDS", "dP (MFMA) -> LDS", "dS rows, shifts published", "dQ MFMAs", "partial sums -> LDS", "fold, dQ -> HBM"])
+report("backward, key role", bwd[half:], ["loads -> LDS", "dP of the block's keys (MFMA)", "wait for the shifts", "dS, P of the block -> LDS", "dV / dK MFMAs", "dV / dK -> HBM"])
+print("key role: entry %.2f us after the first query-role entry (median)" % float(np.median(bwd[half:, 0]) - bwd[:half, 0].min()))

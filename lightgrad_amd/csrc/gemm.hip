@@ -147,7 +147,10 @@ constexpr int gemm_lds_floats() {
 
 // The kernel body lives in gemm_tile_body.inc and is included textually: here as the whole kernel, and twice - once per
 // product - in the two-product launch below.
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1>
+// XT: 1 = three products on one op(A) (lg_gemm_multi3_f32), 2 = K through three B operands (lg_gemm_kseg3_f32).  Separate
+// instantiations: as run-time branches of the common kernel their few instructions and argument loads cost every GEMM launch
+// 0.4 - 1 us (the MLP step 59.9 -> 62.3 us), on the path in front of a workgroup's first global load.
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VA, bool VB, int PD, int KG = 1, int XT = 0>
 __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
 #define LG_TILE_OWNS_LDS 1
 #define LG_TILE_BID blockIdx.x
@@ -166,7 +169,7 @@ template <int PD, bool SECOND_BKC = false>
 __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, GemmArgs second) {
     constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, SECOND_BKC, 1>();
     __shared__ __attribute__((aligned(16))) float lds[L1 > L2 ? L1 : L2];
-    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
+    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1, XT = 0;
     constexpr bool VA = true, VB = true;
 #define LG_TILE_OWNS_LDS 0
     if (int(blockIdx.x) < first.nwg) {
@@ -243,7 +246,7 @@ static_assert(sizeof(GemmGroup) <= 4096, "the group travels as kernel arguments"
 template <int PD>
 __global__ void __launch_bounds__(256) sgemm_group_wgrad(GemmGroup grp) {
     __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<64, 64, 32, false, false, 1>()];
-    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1;
+    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1, XT = 0;
     constexpr bool VA = true, VB = true, AKC = false, BKC = false;
     if (int(blockIdx.x) < grp.cs_wgs) {
         // column-sum role: 64 columns per workgroup, four row groups of 64 threads (row group q takes rows q, q + 4, ...), eight
@@ -289,6 +292,11 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     dim3 grid(g.nwg), block(WM * WN * KG * 64);
     hipStream_t s = rt().stream;
     constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 1;
+    if constexpr (kHasExtras<BM, BN>) {
+        // (the entry points have checked: multi comes K-contiguous on both sides, seg_k with an N-contiguous B, float4 staging)
+        if constexpr (AKC && BKC)  { if (g.multi) { hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG, 1>), grid, block, 0, s, g); return; } }
+        if constexpr (AKC && !BKC) { if (g.seg_k) { hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG, 2>), grid, block, 0, s, g); return; } }
+    }
     if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG>), grid, block, 0, s, g);
     else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1, KG>), grid, block, 0, s, g);
     else if (vb)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, false, true, 1, KG>), grid, block, 0, s, g);
@@ -840,6 +848,7 @@ extern "C" int lg_gemm_multi3_f32(int transA, int transB, int64_t M, int64_t N, 
     LG_ARG(B && C && B[0] && B[1] && B[2] && C[0] && C[1] && C[2], "lg_gemm_multi3_f32: NULL operand");
     LG_ARG(bias == nullptr || (bias[0] && bias[1] && bias[2]), "lg_gemm_multi3_f32: three bias rows or none");
     LG_ARG(!lg::pair_state().active, "lg_gemm_multi3_f32: not inside a pair bracket");
+    LG_ARG(transA == 0 && transB == 1, "lg_gemm_multi3_f32: x @ W^T only (transA = 0, transB = 1)");
     GemmArgs x{};
     x.multi = 1;
     for (int i = 0; i < 3; ++i) {
@@ -858,6 +867,7 @@ extern "C" int lg_gemm_kseg3_f32(int transA, int transB, int64_t M, int64_t N, i
     LG_ARG(seg_k >= 64 && seg_k % 64 == 0, "lg_gemm_kseg3_f32: seg_k = %lld must be a positive multiple of 64", (long long)seg_k);
     LG_ARG(!(accumulate && addend), "lg_gemm_kseg3_f32: accumulate or addend, not both");
     LG_ARG(!lg::pair_state().active, "lg_gemm_kseg3_f32: not inside a pair bracket");
+    LG_ARG(transA == 0 && transB == 0, "lg_gemm_kseg3_f32: g @ W only (transA = 0, transB = 0)");
     GemmArgs x{};
     x.seg_k = int(seg_k);
     // at the end of operand i the running pointer stands at B[i] + seg_k * step, step = 1 along a K-contiguous B, ldb otherwise

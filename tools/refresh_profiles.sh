@@ -27,6 +27,7 @@ step timeline 100 "python tools/gemm_timeline.py > $out/gemm_timeline.txt 2>&1";
 step berttrace 300 "rocprofv3 --kernel-trace --output-format csv -d $out/berttrace -- python3 tools/bert_bench.py --replays 6 > $out/berttrace.log 2>&1"
 python tools/bert_bench.py --trace $out/berttrace/*/*_kernel_trace.csv > $out/bert_step_trace.txt; tail -30 $out/bert_step_trace.txt
 step bertbench 200 "python tools/bert_bench.py > $out/bert_bench.txt 2>&1; echo '--- LIGHTGRAD_GRAD_GROUP=0 (weight gradients launched where the tape makes them, dW and dx paired)' >> $out/bert_bench.txt; LIGHTGRAD_GRAD_GROUP=0 python tools/bert_bench.py >> $out/bert_bench.txt 2>&1"; cat $out/bert_bench.txt
+step attntl 100 "python tools/attn_timeline.py > $out/attn_timeline.txt 2>&1"; cat $out/attn_timeline.txt
 step bertgemm 100 "python tools/bert_gemm_bench.py > $out/bert_gemm_bench.txt 2>&1"; cat $out/bert_gemm_bench.txt
 step cebench 100 "python tools/ce_bench.py > $out/ce_bench.txt 2>&1; LG_CE_HELD=0 python tools/ce_bench.py >> $out/ce_bench.txt 2>&1"; cat $out/ce_bench.txt
 step rehearse 400 "python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-cpu-baseline > $out/bench_rehearsal_two_ranks_one_gpu.json 2> $out/bench_rehearsal.err"; tail -c 300 $out/bench_rehearsal_two_ranks_one_gpu.json

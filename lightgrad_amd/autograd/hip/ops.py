@@ -1023,6 +1023,24 @@ def _table_rows_grad(table, shape, idx, out_grad):
     return _scatter_add_rows(shape, idx, out_grad)
 
 
+_TILED_IDS = {}
+
+
+def _tiled_ids(ids, shape):
+    """the id tensor `ids` repeated along leading axes up to `shape`, as a dense tensor of its own (made once per id tensor and
+    shape: position ids are constants of a model)"""
+    key = (id(ids.data), ids._offset, ids._shape, tuple(shape))
+    hit = _TILED_IDS.get(key)
+    if hit is not None and hit[0]() is ids.data:
+        return hit[1]
+    lead = len(shape) - len(ids._shape)
+    tiled = HipTensor(ids.data, tuple(shape), (0,) * lead + tuple(ids._strides), ids._offset, ids._dtype, requires_grad=False).contiguous()
+    if len(_TILED_IDS) > 64:
+        _TILED_IDS.clear()
+    _TILED_IDS[key] = (weakref.ref(ids.data), tiled)
+    return tiled
+
+
 @HipTensor.register_op()
 class embedding_sum(Function):
     """ (t0[ids0] + t1[ids1]) + t2[ids2] in one pass: the word, position and token-type lookups of a BERT embedding layer and
@@ -1056,9 +1074,10 @@ class embedding_sum(Function):
                 grads.append(None)
                 continue
             g = out_grad
-            if i._shape != ids[0]._shape:                               # ids shared by leading axes: their rows' gradients add up
-                lead = len(ids[0]._shape) - len(i._shape)
-                g = g.sum(axis=tuple(range(lead)), keepdims=False)
+            if i._shape != ids[0]._shape:
+                # ids shared by leading axes (position ids of a batch): every output row is scattered with its own copy of the id -
+                # the scatter-add sums the repeats in position order, no separate sum over the batch in front of it
+                i = _tiled_ids(i, ids[0]._shape)
             grads.append(_table_rows_grad(table, shape, i, g))
         return tuple(grads)
 

@@ -259,6 +259,34 @@ def test_embedding_gather_and_scatter_add(hip):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5, err_msg=str((n_ids, hot)))
 
 
+def test_attention_c_abi_argument_checks(hip):
+    """lg_attention_*: unsupported sizes, pitches below heads * d, misaligned operands and NULL pointers are refused with a text"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    b, s, heads, d = 1, 64, 2, 32
+    w = heads * d
+    q, k, v, o = (hip.from_numpy(np.zeros((b, s, w), np.float32), requires_grad=False) for _ in range(4))
+    p = hip.from_numpy(np.zeros((b, heads, s, s), np.float32), requires_grad=False)
+    ok = lambda **kw: lib.lg_attention_fwd_f32(kw.get("q", q.ptr), kw.get("ld", w), s * w, k.ptr, w, s * w, v.ptr, w, s * w, o.ptr, w, s * w,     # noqa: E731
+                                               kw.get("p", p.ptr), b, heads, kw.get("s", s), kw.get("d", d), 0.5)
+    assert lib.lg_attention_supported(64, 32) == 1 and lib.lg_attention_supported(48, 32) == 0 and lib.lg_attention_supported(256, 64) == 0
+    assert lib.lg_attention_supported(128, 48) == 0
+    assert ok() == 0
+    assert ok(s=48) == -1 and b"unsupported" in lib.lg_last_error()
+    assert ok(d=16) == -1
+    assert ok(ld=w - 4) == -1 and b"row pitch" in lib.lg_last_error()
+    assert ok(q=q.ptr + 4) == -1 and b"aligned" in lib.lg_last_error()
+    assert ok(p=None) == -1
+    assert lib.lg_attention_bwd_f32(q.ptr, w, s * w, k.ptr, w, s * w, v.ptr, w, s * w, o.ptr, w, s * w, p.ptr, q.ptr, w, s * w, k.ptr, w, s * w,
+                                    None, w, s * w, b, heads, s, d, 0.5) == -1
+    ids = hip.from_numpy(np.zeros((6,), np.int32), requires_grad=False)
+    t = hip.from_numpy(np.zeros((4, 8), np.float32), requires_grad=False)
+    out = hip.from_numpy(np.zeros((6, 8), np.float32), requires_grad=False)
+    assert lib.lg_gather_sum3_rows_f32(t.ptr, ids.ptr, 6, 4, t.ptr, ids.ptr, 4, 4, t.ptr, ids.ptr, 6, 4, 4, out.ptr, 6, 8) == -1
+    assert b"divide" in lib.lg_last_error()
+    assert lib.lg_gather_sum3_rows_f32(t.ptr, ids.ptr, 6, 4, t.ptr, ids.ptr, 3, 4, t.ptr, ids.ptr, 6, 4, 2, out.ptr, 6, 8) == -1
+
+
 @pytest.mark.parametrize("b,s,hidden,heads,d", [(8, 128, 128, 2, 64), (2, 64, 96, 2, 32), (1, 32, 40, 3, 64)])
 def test_self_attention_node(hip, b, s, hidden, heads, d):
     """projections + attention as one node (one launch for q / k / v, one for the attention; backward: one attention launch, ONE

@@ -126,6 +126,67 @@ def test_c_abi_accumulate_and_errors(hip):
     assert lib.lg_free(ctypes.c_void_p(12345)) == -1
 
 
+def test_c_abi_three_products_segmented_k_and_activation(hip):
+    """lg_gemm_multi3_f32 (three x @ W_i^T + b_i on separately allocated weights, results as column blocks of one buffer),
+    lg_gemm_kseg3_f32 (one product whose K runs through three operands; plain, accumulate, addend) and lg_gemm_act_f32 (gelu /
+    gelu' in the epilogue) through the raw C ABI against float64, with their argument checks"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(21)
+    ptr3 = lambda *ts: (ctypes.c_void_p * 3)(*[t if isinstance(t, int) else t.ptr for t in ts])      # noqa: E731
+    M, K, N = 200, 96, 128
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    ws = [rng.uniform(-1, 1, (N, K)).astype(np.float32) for _ in range(3)]
+    bs = [rng.uniform(-1, 1, (N,)).astype(np.float32) for _ in range(3)]
+    tx, tws, tbs = hip.from_numpy(x), [hip.from_numpy(w) for w in ws], [hip.from_numpy(b) for b in bs]
+    packed = hip.from_numpy(np.full((M, 3 * N + 4), 7.0, np.float32))               # row pitch 3N + 4: the last 4 columns stay
+    base = packed.ptr
+    assert lib.lg_gemm_multi3_f32(0, 1, M, N, K, tx.ptr, K, ptr3(*tws), K, ptr3(base, base + 4 * N, base + 8 * N), 3 * N + 4, ptr3(*tbs)) == 0
+    got = packed.numpy()
+    for i in range(3):
+        ref = x.astype(np.float64) @ ws[i].astype(np.float64).T + bs[i]
+        assert rel_err(got[:, i * N:(i + 1) * N], ref) <= 2e-6, i
+    np.testing.assert_array_equal(got[:, 3 * N:], 7.0)
+    assert lib.lg_gemm_multi3_f32(0, 1, M, N, K, tx.ptr, K, ptr3(*tws), K, ptr3(base, base + 4 * N, base + 8 * N), 3 * N + 4, None) == 0
+    assert rel_err(packed.numpy()[:, N:2 * N], x.astype(np.float64) @ ws[1].astype(np.float64).T) <= 2e-6
+    assert lib.lg_gemm_multi3_f32(1, 1, M, N, K, tx.ptr, K, ptr3(*tws), K, ptr3(base, base + 4 * N, base + 8 * N), 3 * N + 4, None) == -1
+    assert b"transA = 0" in lib.lg_last_error()
+    # K through three operands: g (M, 3 * seg) @ [v0; v1; v2], v_i (seg, N2) allocated apart
+    seg, N2 = 128, 72
+    g = rng.uniform(-1, 1, (M, 3 * seg)).astype(np.float32)
+    vs = [rng.uniform(-1, 1, (seg, N2)).astype(np.float32) for _ in range(3)]
+    old = rng.uniform(-1, 1, (M, N2)).astype(np.float32)
+    tg, tvs = hip.from_numpy(g), [hip.from_numpy(v) for v in vs]
+    ref = g.astype(np.float64) @ np.concatenate(vs, axis=0).astype(np.float64)
+    out = hip.from_numpy(old.copy())
+    assert lib.lg_gemm_kseg3_f32(0, 0, M, N2, seg, tg.ptr, 3 * seg, ptr3(*tvs), N2, out.ptr, N2, 0, None, 0) == 0
+    assert rel_err(out.numpy(), ref) <= 2e-6
+    assert lib.lg_gemm_kseg3_f32(0, 0, M, N2, seg, tg.ptr, 3 * seg, ptr3(*tvs), N2, out.ptr, N2, 1, None, 0) == 0
+    assert rel_err(out.numpy(), 2 * ref) <= 2e-6
+    out2, told = hip.from_numpy(np.zeros((M, N2), np.float32)), hip.from_numpy(old)
+    assert lib.lg_gemm_kseg3_f32(0, 0, M, N2, seg, tg.ptr, 3 * seg, ptr3(*tvs), N2, out2.ptr, N2, 0, told.ptr, N2) == 0
+    assert rel_err(out2.numpy(), ref + old) <= 2e-6
+    assert lib.lg_gemm_kseg3_f32(0, 0, M, N2, 96, tg.ptr, 3 * seg, ptr3(*tvs), N2, out.ptr, N2, 0, None, 0) == -1
+    assert b"multiple of 64" in lib.lg_last_error()
+    # activation in the epilogue
+    gelu = lambda t: 0.5 * t * (1.0 + np.tanh(t * 0.7978845608 * (1.0 + 0.044715 * t * t)))             # noqa: E731
+    pre, act = hip.from_numpy(np.zeros((M, N), np.float32)), hip.from_numpy(np.zeros((M, N), np.float32))
+    assert lib.lg_gemm_act_f32(0, 1, M, N, K, tx.ptr, K, tws[0].ptr, K, pre.ptr, N, tbs[0].ptr, L.ACT_GELU, act.ptr, N) == 0
+    ref_pre = x.astype(np.float64) @ ws[0].astype(np.float64).T + bs[0]
+    assert rel_err(pre.numpy(), ref_pre) <= 2e-6 and rel_err(act.numpy(), gelu(ref_pre)) <= 2e-6
+    np.testing.assert_allclose(act.numpy(), gelu(pre.numpy().astype(np.float64)), rtol=2e-6, atol=1e-7)     # gelu of the stored pre-activation
+    up = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    dpre, tup = hip.from_numpy(np.zeros((M, K), np.float32)), hip.from_numpy(up)
+    aux = hip.from_numpy(rng.uniform(-2, 2, (M, K)).astype(np.float32))
+    assert lib.lg_gemm_act_f32(0, 0, M, K, N, tup.ptr, N, tws[0].ptr, K, dpre.ptr, K, None, L.ACT_GELU_BWD, aux.ptr, K) == 0
+    t = aux.numpy().astype(np.float64)
+    th = np.tanh(t * 0.7978845608 * (1.0 + 0.044715 * t * t))
+    dgelu = 0.5 * (1.0 + th) + 0.5 * t * (1.0 - th * th) * 0.7978845608 * (1.0 + 0.134145 * t * t)
+    assert rel_err(dpre.numpy(), (up.astype(np.float64) @ ws[0].astype(np.float64)) * dgelu) <= 2e-6
+    assert lib.lg_gemm_act_f32(0, 0, M, K, N, tup.ptr, N, tws[0].ptr, K, dpre.ptr, K, tbs[0].ptr, L.ACT_GELU_BWD, aux.ptr, K) == -1
+    assert lib.lg_gemm_act_f32(0, 0, M, K, N, tup.ptr, N, tws[0].ptr, K, dpre.ptr, K, None, 7, aux.ptr, K) == -1
+
+
 def test_4096_forward_backward_properties(hip):
     """BASELINE config #2 at full size: y = A @ B; y.backward(allow_fill=True)."""
     n = 4096

@@ -368,8 +368,9 @@ int lg_gemm_pair_end(void);
  * lg_gemm_rowsum_f32 calls of the form dW (+ db) = g^T @ x (transA = 1, transB = 0, one matrix, at most 1024 output tiles of
  * 64 x 64) are prepared and QUEUED instead of launched (up to 14), and so are lg_layernorm_param_grads_f32 calls (up to 8) and
  * lg_scatter_add_rows_f32 calls of at most 4096 ids (up to 4; one more launch for these two kinds together);
- * anything else inside the bracket runs as usual.  The queue outlives the bracket: lg_gemm_group_flush launches it - one
- * GEMM kernel, one LayerNorm kernel.  It is also launched when full, when a call writes where a queued one writes, and
+ * anything else inside the bracket runs as usual.  The queue outlives the bracket: lg_gemm_group_flush launches it - ONE
+ * kernel: the products, and behind them in the same grid the LayerNorm / scatter jobs (a launch of their own only when one of
+ * them writes where a product writes: call order is kept then).  It is also launched when full, when a call writes where a queued one writes, and
  * before lg_sync, lg_memcpy_d2h, lg_graph_launch and the end of a capture.  Values are those of the immediate launches up to
  * rounding (a queued product always takes the 64 x 64 tile; launched at once it might split K differently); what changes is
  * WHEN they are computed: the caller must keep the queued calls' operands alive and unchanged and must not read

@@ -291,7 +291,10 @@ template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, int KG>
 static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     dim3 grid(g.nwg), block(WM * WN * KG * 64);
     hipStream_t s = rt().stream;
-    constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 1;
+    // K-tiles in flight between global memory and LDS.  The large tiles ran with ONE until the end of round 3 ("enough MFMAs per
+    // K-tile to cover the latency"): with two, 4096^3 NN 140.9 -> 143.3, NT 143.0 -> 146.6 TFLOP/s on the 256 x 256 tile (TN 138,
+    // unchanged: both its operands come out of LDS as single floats), 132 -> 136-137 on the 128 x 128 tile; three spills.
+    constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 2;
     if constexpr (kHasExtras<BM, BN>) {
         // (the entry points have checked: multi comes K-contiguous on both sides, seg_k with an N-contiguous B, float4 staging)
         if constexpr (AKC && BKC)  { if (g.multi) { hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG, 1>), grid, block, 0, s, g); return; } }

@@ -1,3 +1,5 @@
+// LAB - not part of the library (measured and not kept: profiles/r3/shortk_lab.txt).  It was built as one more translation unit of
+// lightgrad_amd/csrc (copy it there, add it to CORE_SRCS, declare shortk_wants / shortk_launch in common.h and call them from gemm_impl).
 // C[M x N] = A[M x K] @ B[N x K]^T + bias for a SHORT K (<= 128) and a very wide N: the projection of a hidden state onto
 // a vocabulary (tiny-BERT's decoder, reference examples/bert.py:226-227: 1024 x 30522 logits from K = 128).
 //

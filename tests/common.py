@@ -113,3 +113,8 @@ def rel_frobenius(got, ref):
     """||got - ref|| / ||ref|| in float64"""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300))
+
+
+# one encoder layer of BERT at sizes the fused attention kernels take (d = 32, 32 positions): tests/dist_rank_worker.py `bert` mode
+DIST_BERT_CFG = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=60,
+                     max_position_embeddings=32, type_vocab_size=2)

@@ -7,6 +7,8 @@ the test box.  Modes:
                --comm p2p    collectives through peer-mapped device memory (dist.PeerWindowCommunicator, csrc/p2p.hip);
                              with --fused 1 the exchange rides inside the optimizer launch, with --graph 1 the steps after
                              the first are replayed from a hipGraph
+  bert         one encoder layer of BERT with its fused blocks (attention node, feed-forward node, embedding sum) under DataParallel with
+               the peer-window exchange inside the optimizer launch: two steps on per-rank batches; writes rank<r>.npz
   collectives  all-reduce SUM / MAX, broadcast, barrier of the peer-window communicator on awkward sizes, checked in place
   lost_peer    rank 1 never joins a collective: rank 0 must get HipError (LG_ECOMM) at its next synchronisation, not hang
 """
@@ -116,6 +118,60 @@ def train(args, rank, world):
         dist.destroy_process_group()
 
 
+from common import DIST_BERT_CFG as BERT_CFG  # noqa: E402
+
+
+def bert_batch(rank):
+    rng = np.random.RandomState(900 + rank)
+    return rng.randint(0, BERT_CFG["vocab_size"], (2, 32)).astype(np.int32), rng.randint(0, BERT_CFG["vocab_size"], (64,)).astype(np.int64)
+
+
+def bert_train(args, rank, world):
+    import importlib.util
+    import lightgrad_amd as light
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.dist import DataParallel
+    spec = importlib.util.spec_from_file_location("bert_example", os.path.join(ROOT, "examples", "bert.py"))
+    bert = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bert)
+    comm = make_comm("p2p", rank, world)
+    np.random.seed(300 + rank)                     # different init per rank: the broadcast must fix it
+    model = bert.BertForMaskedLM(**BERT_CFG).map_parameters(lambda p: p.hip())
+    dp = DataParallel(model.parameters(), comm, flatten=True)
+    w_start = {n: p.numpy().copy() for n, p in model.named_parameters()}
+    opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, grad_scale=dp.grad_scale, fused=True, device_step=True)
+    dp.attach(opt)
+    assert dp._exchange_in_optimizer
+    ids, labels = bert_batch(rank)
+    tids, tlabels = HipTensor.from_numpy(ids, requires_grad=False), HipTensor.from_numpy(labels, requires_grad=False)
+    fused_nodes = set()
+    losses, g_sum = [], None
+    for it in range(args.steps):
+        logits = model(tids)
+        loss = light.loss.cross_entropy(logits.reshape(-1, BERT_CFG["vocab_size"]), tlabels)
+        node, seen = logits.ctx, set()
+        stack = [loss.ctx]
+        while stack:                               # which tape nodes did this model run on?
+            f = stack.pop()
+            if f is None or id(f) in seen:
+                continue
+            seen.add(id(f))
+            fused_nodes.add(f.__class__.__name__)
+            stack.extend(getattr(t, "ctx", None) for t in f._parents if hasattr(t, "ctx"))
+        opt.zero_grad()
+        loss.backward()
+        dp.sync_gradients()
+        opt.step()
+        if it == 0:
+            g_sum = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}     # the bucket holds the summed gradient
+        losses.append(loss.item())
+    np.savez(os.path.join(args.out, "rank%d.npz" % rank), ids=ids, labels=labels, losses=np.asarray(losses),
+             digest=np.asarray(dp.parameter_digest()), nodes=np.asarray(sorted(fused_nodes)),
+             **{"w0/" + n: v for n, v in w_start.items()}, **{"g/" + n: v for n, v in g_sum.items()},
+             **{"wf/" + n: p.numpy() for n, p in model.named_parameters()})
+    comm.close()
+
+
 def collectives(args, rank, world):
     from lightgrad_amd import HipTensor
     from lightgrad_amd.autograd.hip import HipDevice
@@ -210,7 +266,7 @@ if __name__ == "__main__":
     a.overlap, a.fused, a.graph = bool(a.overlap), bool(a.fused), bool(a.graph)
     a.dims = tuple(int(v) for v in a.dims.split(","))
     try:
-        {"train": train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+        {"train": train, "bert": bert_train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
     except BaseException:
         import traceback
         traceback.print_exc()

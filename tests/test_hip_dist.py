@@ -158,3 +158,45 @@ def test_four_ranks_on_one_device(spawn_ranks, tmp_path):
 def test_a_lost_peer_is_an_error_not_a_hang(spawn_ranks, tmp_path):
     res = _run(spawn_ranks, tmp_path, "--mode", "lost_peer", env={"LG_P2P_TIMEOUT_MS": "300"}, wait_for_all=True, timeout=120)
     assert "lost peer reported" in res["outputs"][0], res["outputs"][0]
+
+
+def test_two_ranks_bert_layer_with_fused_blocks(spawn_ranks, tmp_path):
+    """BASELINE configs 4 + 5 together: an encoder layer of BERT (self-attention node, feed-forward node, embedding sum, LayerNorms,
+    masked-LM cross-entropy) data parallel over two rank processes, the gradient exchange inside the multi-tensor optimizer
+    launch.  Replicas start from rank 0's parameters and stay bit-identical; the reduced gradient is the sum of what the numpy
+    CPU backend gets for the two batches from the same parameters."""
+    import importlib.util
+    import lightgrad_amd as light
+    from lightgrad_amd import CpuTensor
+    _run(spawn_ranks, tmp_path, "--mode", "bert", "--steps", 2, env={"LIGHTGRAD_TEST_WINDOW_FLOATS": str(1 << 17)})
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    names = sorted(k[3:] for k in r0.files if k.startswith("w0/"))
+    assert len(names) > 20
+    for n in names:
+        np.testing.assert_array_equal(r0["w0/" + n], r1["w0/" + n], err_msg=n)
+        np.testing.assert_array_equal(r0["g/" + n], r1["g/" + n], err_msg=n)
+        np.testing.assert_array_equal(r0["wf/" + n], r1["wf/" + n], err_msg=n)
+        assert not np.array_equal(r0["wf/" + n], r0["w0/" + n]) or ".key.bias" in n, n          # two updates happened
+    assert r0["digest"] == r1["digest"]
+    assert {"self_attention", "feed_forward", "embedding_sum", "layer_norm"} <= set(r0["nodes"].tolist())     # the fused blocks ran
+    assert not np.array_equal(r0["losses"], r1["losses"])
+    spec = importlib.util.spec_from_file_location("bert_example", os.path.join(ROOT, "examples", "bert.py"))
+    bert = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bert)
+    from common import DIST_BERT_CFG as BERT_CFG
+    total = {n: 0.0 for n in names}
+    for r in (r0, r1):
+        model = bert.BertForMaskedLM(**BERT_CFG)
+        model.load_parameters({n: r0["w0/" + n] for n in names})
+        logits = model(CpuTensor.from_numpy(r["ids"], requires_grad=False))
+        loss = light.loss.cross_entropy(logits.reshape(-1, BERT_CFG["vocab_size"]), CpuTensor.from_numpy(r["labels"], requires_grad=False))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), r["losses"][0], rtol=1e-5)
+        for n, p in model.named_parameters():
+            total[n] = total[n] + p.grad.numpy().astype(np.float64)
+    for n in names:
+        ref, got = total[n], r0["g/" + n].astype(np.float64)
+        if ".key.bias" in n:                                  # mathematically zero
+            assert np.abs(got).max() < 1e-6
+            continue
+        assert np.linalg.norm(got - ref) <= 2e-5 * np.linalg.norm(ref) + 1e-9, (n, np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--exchange-timeout", type=float, default=180.0,
                     help="N > 1, --comm-dispatch auto: seconds an in-graph form of the exchange may take (calibration or full run) "
                          "before the result of the host-launched form, measured first, is printed and the job ends")
+    ap.add_argument("--comm-open-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a form of communicator (RCCL, peer windows, host-staged) gets to come up on every rank before "
+                         "all ranks drop it and go on with the next one")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 on a box with ONE GPU: every rank binds device 0 and the ranks exchange through peer-mapped device "
                          "memory (RCCL refuses a second rank on a device, hipIpc handles are per process) - the multi-rank code of this "
@@ -179,6 +182,72 @@ def dry_rank(args, rank, world):
 
 
 # ---------------------------------------------------------------------------------------------------------- GPU ranks
+def preflight_report(lib, L, rank, world):
+    """what this rank's device sees of the others (pure queries): the SCALE line then explains itself"""
+    import ctypes
+    n, dev = ctypes.c_int(0), ctypes.c_int(-1)
+    lib.lg_device_count(ctypes.byref(n))
+    L.check(lib.lg_device(ctypes.byref(dev)))
+    names = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}
+    m = min(n.value, max(world, 1))
+    access, links, hop_counts = [], [], []
+    for a in range(m):                   # hipDeviceCanAccessPeer / hipExtGetLinkTypeAndHopCount for every pair of the job's devices
+        row_a, row_l, row_h = [], [], []
+        for b in range(m):
+            can, kind, hops = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(-1)
+            ok = lib.lg_peer_info(a, b, ctypes.byref(can), ctypes.byref(kind), ctypes.byref(hops)) == 0
+            row_a.append(int(bool(can.value)) if ok else None)
+            row_l.append("self" if a == b else (names.get(kind.value, None if kind.value < 0 else str(kind.value)) if ok else None))
+            row_h.append(hops.value if ok and hops.value >= 0 else None)
+        access.append(row_a)
+        links.append(row_l)
+        hop_counts.append(row_h)
+    return {"rank": rank, "device": dev.value, "devices_visible": n.value, "enough_devices": n.value >= world,
+            "can_access_peer": access, "link_type": links, "hops": hop_counts}
+
+
+def open_job_communicators(args, rank, world, L):
+    """-> (bookkeeping communicator, peer-window communicator or None, {name: comm}, {name: why not})"""
+    from lightgrad_amd.dist import RcclCommunicator, PeerWindowCommunicator, open_communicators, peer_window_selftest
+    T = args.comm_open_timeout
+    simulate = os.environ.get("LG_BENCH_FAIL_RCCL", "")            # tests of the fallback: "init", "init:<rank>", "hang"
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+
+    def open_rccl():
+        if simulate.startswith("init") and (":" not in simulate or int(simulate.split(":")[1]) == rank):
+            raise L.HipError("simulated RCCL initialisation failure (LG_BENCH_FAIL_RCCL=%s)" % simulate)
+        if simulate:                                    # "hang", or a rank whose peer failed: what ncclCommInitRank does then
+            time.sleep(10 ** 6)
+        return RcclCommunicator(rank, world, rendezvous_timeout=T, selftest_timeout=max(5.0, T / 2))
+
+    def open_peer():
+        return peer_window_selftest(PeerWindowCommunicator(rank, world, rendezvous_timeout=T))
+
+    openers = []
+    if not rehearsal or simulate:                       # ranks sharing ONE GPU: RCCL refuses the second rank - not even tried
+        openers.append(("rccl", open_rccl))
+    if world > 1 or args.comm_dispatch in ("auto", "p2p"):     # world > 1: always - it carries the bookkeeping when RCCL cannot
+        openers.append(("peer", open_peer))
+    comms, why_not = open_communicators(rank, world, openers, timeout=T)
+    if not comms:
+        def open_host():
+            import datetime
+            import torch.distributed as dist
+            from lightgrad_amd.dist import HostStagedCommunicator, _c_stdout_to_stderr
+            with _c_stdout_to_stderr():
+                dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(30.0, T)))
+                c = HostStagedCommunicator()
+                c.barrier()
+            return c
+        more, why_more = open_communicators(rank, world, [("host", open_host)], timeout=max(60.0, T) + 120.0)   # first `import torch` on a fresh box: minutes
+        comms.update(more)
+        why_not.update(why_more)
+    comm = comms.get("rccl") or comms.get("peer") or comms.get("host")
+    if comm is None:
+        raise L.HipError("no form of the gradient exchange works on this node: %s" % json.dumps(why_not))
+    return comm, comms.get("peer"), comms, why_not
+
+
 def gpu_rank(args, rank, world):
     if not os.path.exists(os.path.join(ROOT, "lightgrad_amd", "liblghip.so")) and rank == 0:
         import subprocess            # the built library normally travels with the tree; compile it if it did not
@@ -187,7 +256,7 @@ def gpu_rank(args, rank, world):
     import lightgrad_amd as light
     from lightgrad_amd import HipTensor, CpuTensor
     from lightgrad_amd.autograd.hip import HipDevice, HipGraph, lib as L
-    from lightgrad_amd.dist import RcclCommunicator, PeerWindowCommunicator, SingleProcess, DataParallel
+    from lightgrad_amd.dist import SingleProcess, DataParallel
 
     if args.rehearse_on_one_gpu:
         from lightgrad_amd.dist import shared_gpu_environment
@@ -195,33 +264,23 @@ def gpu_rank(args, rank, world):
     lib = L.lib()                                    # binds HIP device LOCAL_RANK; raises without library / GPU
     info = HipDevice.info()
     multi = world > 1 or args.force_comm
-    # `comm` carries the bench's own bookkeeping (fences, slowest rank's clock) and the RCCL forms of the exchange; `peer` is
-    # the peer-window communicator of the p2p form.  Ranks that share ONE GPU have only the latter (RCCL refuses a second rank
-    # on a device; hipIpc handles are per process) - and between GPUs the peer windows are an extra that must prove itself:
-    # if a rank cannot map a peer's window, or the self-test against RCCL disagrees, every rank drops the form (`peer_error`).
-    peer, peer_error = None, None
-    if args.rehearse_on_one_gpu and world > 1:
-        comm = peer = PeerWindowCommunicator(rank, world)
-    elif multi:
-        comm = RcclCommunicator(rank, world)
-        if args.comm_dispatch in ("auto", "p2p"):
-            try:
-                peer = PeerWindowCommunicator(rank, world)
-                probe = np.random.RandomState(4242 + rank).uniform(-1, 1, 70001).astype(np.float32)
-                via_peer, via_rccl = HipTensor.from_numpy(probe, requires_grad=False), HipTensor.from_numpy(probe, requires_grad=False)
-                peer.allreduce_sum_(via_peer)
-                comm.allreduce_sum_(via_rccl)
-                np.testing.assert_allclose(via_peer.numpy(), via_rccl.numpy(), rtol=1e-5, atol=1e-6)
-            except (L.HipError, AssertionError, TimeoutError, OSError) as e:
-                peer_error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-            agree = HipTensor.from_numpy(np.asarray([0.0 if peer_error is None else 1.0], np.float32), requires_grad=False)
-            comm.allreduce_max_(agree)
-            if agree.numpy()[0] != 0.0:
-                peer_error = peer_error or "another rank could not set the peer windows up"
-                sys.stderr.write("[bench] rank %d: no peer-window exchange (%s)\n" % (rank, peer_error))
-                peer = None
-            if peer is None and args.comm_dispatch == "p2p":
-                raise L.HipError("--comm-dispatch p2p: " + peer_error)
+    # Three forms of communicator, opened so that no rank is left waiting on one that does not work on this node
+    # (dist.open_communicators: every attempt under a timeout, then a vote through the job's rendezvous files):
+    #   rccl  RCCL over xGMI            bookkeeping (fences, slowest rank's clock) + the host-launched / in-graph collective forms
+    #   peer  peer-mapped device memory the hand-written exchange inside the optimizer launch (csrc/p2p.hip); needs no RCCL, and
+    #                                   carries the bookkeeping too when RCCL is not usable - always the case for ranks that
+    #                                   share ONE GPU (RCCL refuses a second rank on a device; hipIpc handles are per process)
+    #   host  D2H + gloo + H2D          last resort: a job that can still report a number
+    # `comm` = the first of them that works everywhere; `why_not` says what happened to the others.
+    peer, peer_error, comms, why_not, preflight = None, None, {}, {}, None
+    if multi:
+        preflight = preflight_report(lib, L, rank, world)
+        comm, peer, comms, why_not = open_job_communicators(args, rank, world, L)
+        peer_error = why_not.get("peer")
+        if peer is None and args.comm_dispatch == "p2p":
+            raise L.HipError("--comm-dispatch p2p: %s" % peer_error)
+        if rank == 0 and why_not:
+            sys.stderr.write("[bench] communicators: using %s; not usable: %s\n" % (type(comm).__name__, json.dumps(why_not)))
     else:
         comm = SingleProcess()
     # rocprofv3 (ROCm 7.2) faults in its HSA queue interceptor when a hipGraph's packet batch crosses the end of the
@@ -260,9 +319,11 @@ def gpu_rank(args, rank, world):
         def forward(self, x):
             return self.l2(self.l1(x.reshape(-1, 784)).relu())
 
-    def mlp_leg(comm_dispatch, n_steps=None, n_warmup=None, quick=False):
+    def mlp_leg(comm_dispatch, n_steps=None, n_warmup=None, quick=False, no_exchange=False):
         """build model / optimizer / graphs and time the training step; raises if a capture fails or the replicas diverge.
-        quick: a calibration run - only the timed steps, none of the side measurements"""
+        quick: a calibration run - only the timed steps, none of the side measurements.
+        no_exchange: the same step in the same graph form WITHOUT the gradient exchange (every rank trains alone; the
+        difference to the real step is what the exchange costs, `exchange_us_per_step`)"""
         n_steps = args.steps if n_steps is None else n_steps
         n_warmup = args.warmup if n_warmup is None else n_warmup
         np.random.seed(0)                                # identical initial weights on every rank (checked by broadcast)
@@ -270,11 +331,14 @@ def gpu_rank(args, rank, world):
         w0 = {n: p.numpy().copy() for n, p in model.named_parameters()}
         model.map_parameters(lambda p: p.hip())
         use_graph = args.dispatch == "graph" and not args.no_fused_optimizer
-        in_optimizer = multi and comm_dispatch == "p2p" and use_graph      # exchange inside the optimizer launch (csrc/p2p.hip)
+        in_optimizer = multi and comm_dispatch == "p2p" and use_graph and not no_exchange     # exchange inside the optimizer launch (csrc/p2p.hip)
         leg_comm = peer if (comm_dispatch == "p2p" or comm is peer) else comm
-        overlap = multi and not in_optimizer and leg_comm is not peer and (comm_dispatch == "graph" or not use_graph)
+        if no_exchange:
+            leg_comm = SingleProcess()
+        streams = multi and leg_comm is comms.get("rccl")            # only RCCL has a communication stream to overlap on
+        overlap = streams and not in_optimizer and (comm_dispatch == "graph" or not use_graph)
         dp = DataParallel(model.parameters(), leg_comm, flatten=use_graph, overlap=overlap)
-        dp.always_sync = args.force_comm                 # world_size 1: still run the exchange
+        dp.always_sync = args.force_comm and not no_exchange        # world_size 1: still run the exchange
         opt = light.optim.AdaBelief(model.parameters(), lr=1e-3, fused=not args.no_fused_optimizer, grad_scale=dp.grad_scale,
                                     device_step=use_graph)
         if use_graph:
@@ -308,7 +372,7 @@ def gpu_rank(args, rank, world):
         if use_graph:
             n_params = len(opt.parameters)
             g_all = None
-            if not multi or comm_dispatch in ("p2p", "graph", "graph-inline"):
+            if not multi or comm_dispatch in ("p2p", "graph", "graph-inline") or (no_exchange and comm_dispatch != "eager"):
                 # ONE graph for the whole step.  With a communicator the all-reduce is part of it - as a forked branch (started on
                 # the communication stream after the last parameter-gradient kernel, joined before the optimizer kernel) or, with
                 # graph-inline, as one more node of the chain on the compute stream.
@@ -316,7 +380,7 @@ def gpu_rank(args, rank, world):
                     g_all = HipGraph()
                     with g_all.capture():
                         graph_loss = eager_step()
-                    comm_in_graph = multi
+                    comm_in_graph = multi and not no_exchange
                 except L.HipError:
                     raise                        # multi: gpu_rank repeats the leg with host-launched collectives
                 opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
@@ -373,7 +437,7 @@ def gpu_rank(args, rank, world):
         assert np.isfinite(final_loss), final_loss
         steps_per_s = world * n_steps / elapsed
         digest = dp.parameter_digest()
-        if multi:                                        # replicas must still be identical
+        if multi and not no_exchange:                    # replicas must still be identical
             d = HipTensor.from_numpy(np.asarray([digest, -digest], np.float32), requires_grad=False)
             comm.allreduce_max_(d)
             dmax, dmin = d.numpy()
@@ -447,12 +511,24 @@ def gpu_rank(args, rank, world):
                     eager_steps_per_s=eager_steps_per_s, dispatched_ops=dispatched_ops, launches_per_step=launches_per_step, long_window=long_window, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
                     unroll=unroll, use_graph=use_graph, overlap=dp.overlap, w0=w0, x_np=x_np, onehot_np=onehot_np)
 
-    def assemble(R, chosen, calibration, fallback_reason, extra):
+    def communicator_fallback():
+        """None when the bookkeeping runs on the first choice (RCCL between GPUs; peer windows for ranks sharing one GPU)"""
+        if not multi or comm is comms.get("rccl") or (args.rehearse_on_one_gpu and "rccl" not in why_not):
+            return None
+        return "RCCL not usable (%s): fences, clocks and the exchange run through %s" % (why_not.get("rccl", "not attempted"), type(comm).__name__)
+
+    def assemble(R, chosen, calibration, fallback_reason, extra, exchange_cost=None):
         """the one JSON line for a finished leg"""
         exchange_comm = peer if (chosen == "p2p" or comm is peer) else comm
         ranks_info = {"world_size": world, "communicator": type(comm).__name__,
+                      "communicator_fallback": communicator_fallback(),
+                      "communicators_not_usable": why_not or None,
+                      "preflight": preflight,
                       "exchange_communicator": type(exchange_comm).__name__ if multi else None,
                       "peer_window_exchange": None if not multi else ("available" if peer is not None else "not available: %s" % peer_error),
+                      "peer_window_memory": peer.memory_kind() if peer is not None else None,
+                      # the step with and without its exchange, same graph form, slowest rank's clock (a SCALE line explains its own efficiency)
+                      "exchange_us_per_step": exchange_cost,
                       "communicator_ranks": (exchange_comm.ranks_seen() if hasattr(exchange_comm, "ranks_seen") else exchange_comm.world_size) if multi else 1,   # what the library itself reports
                       "per_rank_steps_per_sec": [round(v, 2) for v in R["per_rank"]],
                       "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else
@@ -462,7 +538,7 @@ def gpu_rank(args, rank, world):
                                           "(push to the chunk owner, sum in rank order, publish; no collective library, no extra launch)",
                                    "graph": "all-reduce forked inside the captured step, overlapped with the input-gradient GEMM",
                                    "graph-inline": "all-reduce inside the captured step on the compute stream (no branch, no overlap)",
-                                   "eager": "host-launched all-reduce after the replayed forward+backward graph"}.get(chosen, chosen)
+                                   "eager": "host-launched all-reduce (%s) after the replayed forward+backward graph" % type(exchange_comm).__name__}.get(chosen, chosen)
                                   if R["use_graph"] else "host-launched all-reduce on the communication stream, overlapped with backward (eager tape)",
                       "exchange_form": chosen if multi else None,
                       "exchange_calibration_steps_per_sec": calibration or None,
@@ -501,6 +577,21 @@ def gpu_rank(args, rank, world):
         return extras(R["first_losses"], args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel,
                       SingleProcess, wall_max, fence, under_profiler, R["w0"], R["x_np"], R["onehot_np"])
 
+    def exchange_cost_of(mode, guard=None):
+        """us per step that the exchange costs: the same step in the same graph form with and without it (two short runs of
+        equal length, slowest rank's clock)"""
+        try:
+            quick_steps = 5 * min(args.graph_steps, 8)
+            rates = []
+            for no_exchange in (True, False):
+                run = lambda: mlp_leg(mode, n_steps=quick_steps, n_warmup=min(args.warmup, 10), quick=True, no_exchange=no_exchange)["steps_per_s"]
+                rates.append(guard(mode, "exchange cost", run, key="exchange_cost") if guard else run())
+            without, with_ = rates
+            return {"form": mode, "steps_timed": quick_steps, "with_exchange_us": round(1e6 * world / with_, 2),
+                    "without_exchange_us": round(1e6 * world / without, 2), "exchange_us": round(1e6 * world / with_ - 1e6 * world / without, 2)}
+        except (L.HipError, AssertionError) as e:
+            return {"form": mode, "failed": "%s: %s" % (type(e).__name__, e)}
+
     calibration, fallback_reason = {}, None
     if multi and args.comm_dispatch == "auto":
         # Where the all-reduce runs is decided by measurement.  FIRST the form that captures nothing of RCCL - forward+backward
@@ -512,16 +603,13 @@ def gpu_rank(args, rank, world):
         # than 2 % is timed in full (same watchdog) and reported if it is still ahead.  Every decision uses the slowest rank's
         # clock, so all ranks decide alike.
         import threading
-        best, chosen = mlp_leg("eager"), "eager"
-        extra = side_measurements(best)
-        calibration["eager"] = round(best["steps_per_s"], 1)
         state = {"deadline": None, "label": None, "line": None}
 
         def watchdog():
             while True:
                 time.sleep(0.5)
                 if state["deadline"] is not None and time.time() > state["deadline"]:
-                    sys.stderr.write("[bench] rank %d: exchange form %r did not finish within %.0f s - reporting the host-launched form\n"
+                    sys.stderr.write("[bench] rank %d: %r did not finish within %.0f s - reporting what is in hand\n"
                                      % (rank, state["label"], args.exchange_timeout))
                     if rank == 0:
                         print(state["line"])
@@ -529,19 +617,40 @@ def gpu_rank(args, rank, world):
                     sys.stderr.flush()
                     os._exit(args.watchdog_exit_code)   # the stuck collective cannot be recovered in this process: not a success
         threading.Thread(target=watchdog, daemon=True).start()
+        # the first leg has no measured line behind it: if even the host-launched form never comes back, the job still ends,
+        # with a line that says so (value null) and the watchdog's exit code
+        state["line"] = json.dumps({"metric": "mnist_mlp_train_steps_per_sec_batch1024_per_gpu", "value": None, "unit": "steps/s", "n_gpus": world,
+                                    "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+                                    "error": "the host-launched form of the exchange did not finish within %.0f s" % (4 * args.exchange_timeout),
+                                    "ranks": {"world_size": world, "communicator": type(comm).__name__, "communicators_not_usable": why_not or None,
+                                              "preflight": preflight}})
+        state["label"], state["deadline"] = "eager (first leg)", time.time() + 4 * args.exchange_timeout
+        best, chosen = mlp_leg("eager"), "eager"
+        state["deadline"] = None
+        extra = side_measurements(best)
+        calibration["eager"] = round(best["steps_per_s"], 1)
 
-        def guarded(mode, what, fn):
+        def guarded(mode, what, fn, key=None):
             calibration_so_far = dict(calibration)
-            calibration_so_far[mode] = "no answer within %.0f s (%s)" % (args.exchange_timeout, what)
-            state["line"] = json.dumps(assemble(best, chosen, calibration_so_far, "%s: watchdog" % mode, extra))
-            state["label"], state["deadline"] = mode, time.time() + args.exchange_timeout
+            calibration_so_far[key or mode] = "no answer within %.0f s (%s)" % (args.exchange_timeout, what)
+            state["line"] = json.dumps(assemble(best, chosen, calibration_so_far, "%s: watchdog" % (key or mode), extra))
+            state["label"], state["deadline"] = key or mode, time.time() + args.exchange_timeout
             try:
                 return fn()
             finally:
                 state["deadline"] = None
 
-        # the peer-window form first (the cheapest exchange); the forked RCCL branch does not exist for ranks that share a GPU
-        for mode in (["p2p"] if peer is not None else []) + ["graph-inline"] + (["graph"] if comm is not peer else []):
+        # the peer-window form first (the cheapest exchange); in-graph collectives need a device-side communicator, the forked
+        # branch RCCL's communication stream.  After ONE failure of a peer-window form the communicator is dead for good
+        # (lg_p2p_state: every later launch is refused) - its other forms are not tried.
+        candidates = (["p2p"] if peer is not None else []) + (["graph-inline"] if comm is not comms.get("host") else []) \
+            + (["graph"] if comm is comms.get("rccl") else [])
+        peer_lost = False
+        for mode in candidates:
+            uses_peer = mode == "p2p" or comm is peer
+            if peer_lost and uses_peer:
+                calibration[mode] = "not tried: the peer-window communicator failed earlier"
+                continue
             try:
                 quick_steps = 5 * min(args.graph_steps, 8)
                 if os.environ.get("LG_BENCH_SIMULATE_HANG") == mode:          # tests of the watchdog only
@@ -551,6 +660,7 @@ def gpu_rank(args, rank, world):
             except (L.HipError, AssertionError) as e:
                 calibration[mode] = "failed: %s: %s" % (type(e).__name__, e)
                 sys.stderr.write("[bench] rank %d: exchange form %r failed in calibration (%s)\n" % (rank, mode, calibration[mode]))
+                peer_lost = peer_lost or (uses_peer and peer is not None and peer.failed())
                 continue
             if rate > 1.02 * best["steps_per_s"]:
                 try:
@@ -560,7 +670,12 @@ def gpu_rank(args, rank, world):
                 except (L.HipError, AssertionError) as e:
                     fallback_reason = "%s: %s: %s" % (mode, type(e).__name__, e)
                     sys.stderr.write("[bench] rank %d: the full run with exchange form %r failed (%s)\n" % (rank, mode, fallback_reason))
-        out = assemble(best, chosen, calibration, fallback_reason, extra)
+                    peer_lost = peer_lost or (uses_peer and peer is not None and peer.failed())
+        cost = None
+        if not (peer_lost and (chosen == "p2p" or comm is peer)):
+            state["line"] = json.dumps(assemble(best, chosen, calibration, fallback_reason, extra))
+            cost = exchange_cost_of(chosen, guarded)
+        out = assemble(best, chosen, calibration, fallback_reason, extra, cost)
     else:
         modes = {"graph": ["graph", "eager"], "p2p": ["p2p", "eager"]}.get(args.comm_dispatch, [args.comm_dispatch]) if multi else ["graph"]
         R, chosen = None, None
@@ -575,13 +690,24 @@ def gpu_rank(args, rank, world):
                 fallback_reason = "%s: %s: %s" % (mode, type(e).__name__, e)
                 sys.stderr.write("[bench] rank %d: the leg with exchange form %r failed (%s); repeating with %r\n"
                                  % (rank, mode, fallback_reason, modes[k + 1]))
-        out = assemble(R, chosen, calibration, fallback_reason, side_measurements(R))
-    if multi:
-        if peer is not None and peer is not comm:
-            peer.close()
-        comm.close()
+        cost = exchange_cost_of(chosen) if world > 1 else None
+        out = assemble(R, chosen, calibration, fallback_reason, side_measurements(R), cost)
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    if multi:
+        for c in comms.values():
+            try:
+                c.close()
+            except (L.HipError, TimeoutError) as e:
+                sys.stderr.write("[bench] rank %d: closing %s: %s\n" % (rank, type(c).__name__, e))
+        if comms.get("host") is not None:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+    import threading
+    if any(t.name == "lightgrad-open-communicator" and t.is_alive() for t in threading.enumerate()):
+        sys.stderr.flush()               # a communicator attempt was abandoned inside its library: do not run that library's
+        os._exit(0)                      # teardown under it - the result has been printed
 
 
 def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTensor, CpuTensor, HipDevice, HipGraph, DataParallel, SingleProcess,

@@ -63,6 +63,11 @@ typedef struct {
     int32_t  reserved;
 } lg_device_info_t;
 int lg_device_info(lg_device_info_t* out);
+/* Preflight of a multi-GPU job (no counterpart in the reference: its device pool enumerates OpenCL devices and never
+ * relates two of them, opencl/device.py:12-49).  Pure queries, usable before lg_init and without touching `peer`:
+ * can_access = hipDeviceCanAccessPeer(device, peer); link_type = hipExtGetLinkTypeAndHopCount's type (HSA_AMD_LINK_INFO_TYPE:
+ * 0 HyperTransport, 1 QPI, 2 PCIe, 3 InfiniBand, 4 xGMI), hops its hop count; both -1 when the runtime cannot say. */
+int lg_peer_info(int device, int peer, int* can_access, int* link_type, int* hops);
 void* lg_stream(void);                          /* hipStream_t of the library (for liblghip_comm / profilers) */
 int lg_sync(void);                              /* block until the stream is idle */
 

@@ -34,6 +34,10 @@ const char* lg_comm_last_error(void);
 int lg_comm_get_unique_id(char id[LG_COMM_ID_BYTES]);
 int lg_comm_init(int rank, int nranks, const char id[LG_COMM_ID_BYTES]);   /* lg_init must have been called */
 int lg_comm_rank(int* rank, int* nranks);
+/* first collective of a new communicator: all-reduce of 1.0 on the COMMUNICATION stream, awaited by polling an event for at
+ * most `timeout_s` seconds (LG_ECOMM after that, or when the sum is not nranks) - the compute stream has nothing of it queued,
+ * so a job can go on with another form of the exchange (lghip_p2p.h) when a peer fell out during lg_comm_init */
+int lg_comm_selftest(double timeout_s);
 int lg_comm_allreduce_f32(float* buf, int64_t n, int op);                  /* in place, on the compute stream */
 /* overlap: fork = the communication stream waits for everything enqueued so far on the compute stream;
  * allreduce_forked = the collective, in place, on the communication stream; join = the compute stream waits

@@ -14,8 +14,9 @@
  *   consume  a non-owner waits for that flag and reads the sum from its own window
  * so every rank ends with the SAME bits (the owner's sum), the same in every run.  A flag carries the number of exchanges
  * its chunk has been through; each workgroup keeps that count for its chunk in device memory, so a launch recorded in a
- * hipGraph replays correctly, no flag is ever reset and no workgroup waits for another one of its own launch.  A wait gives up after LG_P2P_TIMEOUT_S seconds (a lost peer): the device status flag is raised
- * and the next synchronising call of lghip.h returns LG_ECOMM.
+ * hipGraph replays correctly, no flag is ever reset and no workgroup waits for another one of its own launch.  A wait gives up
+ * after LG_P2P_TIMEOUT_S seconds (a lost peer): the device status flag is raised and the next synchronising call of lghip.h
+ * returns LG_ECOMM; the communicator stays failed from then on (lg_p2p_state).
  *
  * lg_p2p_adam_multi_dev_f32 is lg_adam_multi_dev_f32 (lghip.h) with this exchange in front of the update, in the SAME
  * launch: the data-parallel training step keeps the launch count of the single-GPU step.
@@ -48,6 +49,15 @@ int lg_p2p_export(int rank, int nranks, int64_t capacity_floats, char handle[LG_
 /* map the windows of all peers: `handles` = nranks x LG_P2P_HANDLE_BYTES, ordered by rank (the own entry is ignored) */
 int lg_p2p_connect(const char* handles);
 int lg_p2p_rank(int* rank, int* nranks, int64_t* capacity_floats);
+/* failed: 1 once a wait of this communicator gave up and a synchronising call reported it (LG_ECOMM) - from then on every
+ * lg_p2p_allreduce_f32 / lg_p2p_adam_multi_dev_f32 returns LG_ECOMM without launching, and launches that were enqueued (or
+ * recorded in a hipGraph) before are reported again at the next synchronising call: an exchange that did not happen is never
+ * taken for one that did.  The way out is lg_p2p_disconnect + lg_p2p_free (no barrier with the lost peer) and a new window.
+ * memory_kind: how the window was allocated ("uncached", "fine-grained", "hipMalloc"). */
+int lg_p2p_state(int* failed, char memory_kind[32]);
+/* tests only: pretend every chunk has been through `epoch` exchanges (epochs count modulo 2^32; the wrap is tested by
+ * seeding them just below it).  Same value on every rank, no launch in flight, host barrier between the ranks afterwards. */
+int lg_p2p_debug_seed_epochs(int epoch);
 /* in-place all-reduce of buf[0..n) over the ranks; n may exceed the capacity (then several launches).  Collective:
  * every rank must issue the same sequence of lg_p2p_* launches with the same sizes. */
 int lg_p2p_allreduce_f32(float* buf, int64_t n, int op);

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "lg_init": (c_int, [c_int]),
     "lg_device": (c_int, [POINTER(c_int)]),
     "lg_device_info": (c_int, [POINTER(DeviceInfo)]),
+    "lg_peer_info": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "lg_stream": (c_void_p, []),
     "lg_sync": (c_int, []),
     "lg_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
@@ -128,6 +129,8 @@ P2P_PROTOTYPES = {
     "lg_p2p_export": (c_int, [c_int, c_int, c_int64, c_void_p]),          # char handle[64]
     "lg_p2p_connect": (c_int, [c_void_p]),
     "lg_p2p_rank": (c_int, [POINTER(c_int), POINTER(c_int), _I64P]),
+    "lg_p2p_state": (c_int, [POINTER(c_int), c_void_p]),                   # int* failed, char memory_kind[32]
+    "lg_p2p_debug_seed_epochs": (c_int, [c_int]),
     "lg_p2p_allreduce_f32": (c_int, [c_void_p, c_int64, c_int]),
     "lg_p2p_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
                                           c_double, c_void_p, c_int64, c_double, c_int]),
@@ -140,6 +143,7 @@ COMM_PROTOTYPES = {
     "lg_comm_get_unique_id": (c_int, [c_void_p]),          # char id[128]
     "lg_comm_init": (c_int, [c_int, c_int, c_void_p]),
     "lg_comm_rank": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "lg_comm_selftest": (c_int, [c_double]),
     "lg_comm_allreduce_f32": (c_int, [c_void_p, c_int64, c_int]),
     "lg_comm_fork": (c_int, []),
     "lg_comm_allreduce_forked_f32": (c_int, [c_void_p, c_int64, c_int]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <ctime>
 #include "../../include/lghip.h"
 #include "../../include/lghip_comm.h"
 
@@ -75,6 +76,55 @@ int lg_comm_init(int rank, int nranks, const char id[LG_COMM_ID_BYTES]) {
         LG_CHIP(hipStreamCreateWithPriority(&g_comm_stream, hipStreamNonBlocking, hi));
         LG_CHIP(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
         LG_CHIP(hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming));
+    }
+    return LG_OK;
+}
+
+// The first collective of a new communicator, on the COMMUNICATION stream, awaited by polling an event: a collective that
+// never completes (a peer that fell out during init) is reported after `timeout_s` instead of blocking the caller, and the
+// compute stream - which the other forms of the exchange need - has nothing of it queued.
+int lg_comm_selftest(double timeout_s) {
+    if (!g_comm) { cerr("lg_comm_selftest: communicator not initialised"); return LG_ENOTINIT; }
+    float* token = nullptr;
+    LG_CHIP(hipMalloc(reinterpret_cast<void**>(&token), sizeof(float)));
+    const float one = 1.0f;
+    LG_CHIP(hipMemcpy(token, &one, sizeof(float), hipMemcpyHostToDevice));
+    hipEvent_t done = nullptr;
+    LG_CHIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    {
+        ncclResult_t r = ncclAllReduce(token, token, 1, ncclFloat32, ncclSum, g_comm, g_comm_stream);
+        if (r != ncclSuccess) {
+            cerr("lg_comm_selftest: ncclAllReduce failed: %s", ncclGetErrorString(r));
+            (void)hipEventDestroy(done);
+            (void)hipFree(token);
+            return LG_ECOMM;
+        }
+    }
+    LG_CHIP(hipEventRecord(done, g_comm_stream));
+    const double step_us = 200.0;
+    double waited_us = 0.0;
+    for (;;) {
+        hipError_t q = hipEventQuery(done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            cerr("lg_comm_selftest: hipEventQuery failed: %s", hipGetErrorString(q));
+            return LG_EHIP;                       // token and event are left alone: the stream may still refer to them
+        }
+        if (waited_us > timeout_s * 1e6) {
+            cerr("lg_comm_selftest: the first all-reduce over %d ranks did not complete within %.0f s", g_nranks, timeout_s);
+            return LG_ECOMM;                      // likewise left alone
+        }
+        struct timespec ts = {0, long(step_us * 1000)};
+        nanosleep(&ts, nullptr);
+        waited_us += step_us;
+    }
+    float sum = 0.f;
+    LG_CHIP(hipMemcpy(&sum, token, sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipEventDestroy(done);
+    (void)hipFree(token);
+    if (sum != float(g_nranks)) {
+        cerr("lg_comm_selftest: the all-reduce of 1.0 over %d ranks gave %g", g_nranks, double(sum));
+        return LG_ECOMM;
     }
     return LG_OK;
 }

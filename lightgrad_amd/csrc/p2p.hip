@@ -35,6 +35,7 @@
 #include "adam_common.h"
 #include "../../include/lghip_p2p.h"
 #include <cstdlib>
+#include <vector>
 
 namespace lg {
 
@@ -61,17 +62,28 @@ struct P2PCtx {
 __device__ __forceinline__ void st_sys(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ int  ld_sys(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// wait until *flag has reached epoch `want`; gives up after x.spin_ticks (or at once when an earlier wait gave up).
-// The FIRST wait that gives up leaves a record for the error message: local[2..6] = chunk, epoch wanted, value seen,
-// kind (1 = a peer's push, 2 = the owner's sum), the rank waited for.
+// epochs are counted modulo 2^32 (a chunk reaches 2^31 exchanges after ~36 h at 16.7 k steps/s): "flag has reached want" is
+// the sign of the 32-bit DIFFERENCE, formed in unsigned arithmetic (signed overflow would be undefined behaviour and lets the
+// compiler fold the test into `seen >= want`, true right after the wrap)
+__device__ __forceinline__ bool reached(int seen, int want) { return int32_t(uint32_t(seen) - uint32_t(want)) >= 0; }
+__device__ __forceinline__ int  next_epoch(int done) { return int(uint32_t(done) + 1u); }
+
+// wait until *flag has reached epoch `want`; gives up after x.spin_ticks.  The FIRST wait that gives up leaves a record for
+// the error message: local[2..6] = chunk, epoch wanted, value seen, kind (1 = a peer's push, 2 = the owner's sum), the rank
+// waited for - and marks the communicator dead (local[1], never reset: lg_p2p_free is the only way out).  On a dead
+// communicator every wait returns after 32 polls AND raises the status flag again: a launch that was already enqueued (or is
+// replayed from a hipGraph) after the first report is reported too, never taken for an exchange that happened.
 __device__ __forceinline__ void spin_ge(const int* flag, int want, const P2PCtx& x, int chunk, int kind, int from) {
-    if (ld_sys(flag) - want >= 0) return;
+    if (reached(ld_sys(flag), want)) return;
     const int64_t t0 = wall_clock64();
     for (int n = 1;; ++n) {
         __builtin_amdgcn_s_sleep(1);
-        if (ld_sys(flag) - want >= 0) return;
+        if (reached(ld_sys(flag), want)) return;
         if ((n & 31) == 0) {
-            if (__hip_atomic_load(x.local + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            if (__hip_atomic_load(x.local + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_fetch_or(x.status, LG_STATUS_P2P_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
             if (wall_clock64() - t0 > x.spin_ticks) {
                 if (__hip_atomic_exchange(x.local + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     x.local[2] = chunk; x.local[3] = want; x.local[4] = ld_sys(flag); x.local[5] = kind; x.local[6] = from;
@@ -213,7 +225,7 @@ __device__ __forceinline__ void exchange_chunk(const P2PCtx& x, int epoch, int c
 template <bool kMax>
 __global__ void __launch_bounds__(256) p2p_allreduce(P2PCtx x, float* buf, int64_t n, int pieces, int vec) {
     const int c = blockIdx.x;
-    const int epoch = __hip_atomic_load(x.local + kEpochBase + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const int epoch = next_epoch(__hip_atomic_load(x.local + kEpochBase + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int64_t first = int64_t(c) * pieces * kPiece;
     float last[4];
     exchange_chunk<kMax>(x, epoch, c, buf, first, n, pieces, vec != 0, last);
@@ -239,7 +251,7 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
     const int64_t first = begin + int64_t(blockIdx.x) * seg.pieces * kPiece;
     if (first >= end) return;                                      // workgroup-uniform
     const int chunk = seg.chunk_base[j] + blockIdx.x;
-    const int epoch = __hip_atomic_load(x.local + kEpochBase + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const int epoch = next_epoch(__hip_atomic_load(x.local + kEpochBase + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     int64_t* my_step = step + 2 + step_slot_base + chunk;          // this workgroup's own copy of the optimizer's step number
     int64_t steps_done = 0;
     if (threadIdx.x == 0) {
@@ -295,6 +307,7 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
 // ---- host state ---------------------------------------------------------------------------------------------------------
 struct P2PState {
     bool    exported = false, connected = false;
+    bool    failed = false;                      // a wait gave up and was reported: every later lg_p2p_* launch is refused (LG_ECOMM)
     int     rank = -1, nranks = 0;
     int64_t cap = 0;
     int     max_chunks = 0;
@@ -333,9 +346,12 @@ static P2PCtx make_ctx() {
     return x;
 }
 
-// for the error text of a wait that gave up (runtime.hip: check_device_status, after the stream has been synchronised)
+// for the error text of a wait that gave up (runtime.hip: check_device_status, after the stream has been synchronised);
+// from here on the communicator is FAILED on the host too: no later launch may pass for an exchange (the device-side dead
+// flag makes the waits of already enqueued launches short, this makes new ones impossible)
 void p2p_describe_timeout(char* out, size_t len) {
     P2PState& S = st();
+    S.failed = true;
     int rec[8] = {};
     if (!S.local || hipMemcpy(rec, S.local, sizeof(rec), hipMemcpyDeviceToHost) != hipSuccess) {
         (void)hipGetLastError();
@@ -349,6 +365,15 @@ void p2p_describe_timeout(char* out, size_t len) {
 }  // namespace lg
 
 using namespace lg;
+
+#define LG_P2P_ALIVE(who)                                                                                              \
+    do {                                                                                                               \
+        if (st().failed) {                                                                                             \
+            set_error("%s: this peer-window communicator lost a peer earlier (a wait gave up and was reported): nothing is " \
+                      "exchanged any more - lg_p2p_disconnect / lg_p2p_free, then start over", who);                   \
+            return LG_ECOMM;                                                                                           \
+        }                                                                                                              \
+    } while (0)
 
 extern "C" int lg_p2p_export(int rank, int nranks, int64_t capacity_floats, char handle[LG_P2P_HANDLE_BYTES]) {
     LG_REQUIRE_INIT();
@@ -426,10 +451,34 @@ extern "C" int lg_p2p_rank(int* rank, int* nranks, int64_t* capacity_floats) {
     return LG_OK;
 }
 
+extern "C" int lg_p2p_state(int* failed, char memory_kind[32]) {
+    P2PState& S = st();
+    LG_ARG(S.exported, "lg_p2p_state: no window");
+    if (failed) *failed = S.failed ? 1 : 0;
+    if (memory_kind) snprintf(memory_kind, 32, "%s", S.memory_kind);
+    return LG_OK;
+}
+
+// tests only: pretend every chunk has been through `epoch` exchanges (own window's flags and this rank's counts).  Every
+// rank calls it with the same value while no launch is in flight, and the ranks synchronise on the host before the next one.
+extern "C" int lg_p2p_debug_seed_epochs(int epoch) {
+    LG_REQUIRE_INIT();
+    P2PState& S = st();
+    LG_ARG(S.connected, "lg_p2p_debug_seed_epochs: lg_p2p_export / lg_p2p_connect first");
+    LG_HIP(hipStreamSynchronize(rt().stream));
+    std::vector<int> flags(size_t(S.max_chunks) * kFlag1Stride, epoch);
+    LG_HIP(hipMemcpy(S.window + S.off_flag1, flags.data(), size_t(S.max_chunks) * kFlag1Stride * sizeof(int), hipMemcpyHostToDevice));
+    LG_HIP(hipMemcpy(S.window + S.off_flag2, flags.data(), size_t(S.max_chunks) * sizeof(int), hipMemcpyHostToDevice));
+    LG_HIP(hipMemcpy(S.local + kEpochBase, flags.data(), size_t(S.max_chunks) * sizeof(int), hipMemcpyHostToDevice));
+    LG_HIP(hipDeviceSynchronize());
+    return LG_OK;
+}
+
 extern "C" int lg_p2p_allreduce_f32(float* buf, int64_t n, int op) {
     LG_REQUIRE_INIT();
     P2PState& S = st();
     LG_ARG(S.connected, "lg_p2p_allreduce_f32: lg_p2p_export / lg_p2p_connect first");
+    LG_P2P_ALIVE("lg_p2p_allreduce_f32");
     LG_ARG(n >= 0 && (n == 0 || buf), "lg_p2p_allreduce_f32: bad buffer");
     LG_ARG(op == LG_P2P_SUM || op == LG_P2P_MAX, "lg_p2p_allreduce_f32: unknown op %d", op);
     const P2PCtx x = make_ctx();
@@ -452,6 +501,7 @@ extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v,
     LG_REQUIRE_INIT();
     P2PState& S = st();
     LG_ARG(S.connected, "lg_p2p_adam_multi_dev_f32: lg_p2p_export / lg_p2p_connect first");
+    LG_P2P_ALIVE("lg_p2p_adam_multi_dev_f32");
     LG_ARG(nseg >= 1, "lg_p2p_adam_multi_dev_f32: %d segments", nseg);
     LG_ARG(p && g && m && v && step && offsets, "lg_p2p_adam_multi_dev_f32: NULL pointer");
     for (int j = 0; j < nseg; ++j) LG_ARG(offsets[j + 1] >= offsets[j], "lg_p2p_adam_multi_dev_f32: offsets must be non-decreasing");

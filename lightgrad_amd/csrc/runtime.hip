@@ -132,6 +132,26 @@ int lg_device_count(int* count) {
     return LG_OK;
 }
 
+int lg_peer_info(int device, int peer, int* can_access, int* link_type, int* hops) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    LG_ARG(device >= 0 && device < n && peer >= 0 && peer < n, "lg_peer_info: devices %d, %d of %d visible", device, peer, n);
+    int can = device == peer ? 1 : 0;
+    if (device != peer && hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+    uint32_t type = 0, hop = 0;
+    int t = -1, h = -1;
+    if (device != peer) {
+        if (hipExtGetLinkTypeAndHopCount(device, peer, &type, &hop) == hipSuccess) { t = int(type); h = int(hop); }
+        else (void)hipGetLastError();
+    } else {
+        h = 0;
+    }
+    if (can_access) *can_access = can;
+    if (link_type) *link_type = t;
+    if (hops) *hops = h;
+    return LG_OK;
+}
+
 int lg_init(int device) {
     Runtime& R = rt();
     if (R.ready) {

@@ -148,8 +148,9 @@ def _exchange_unique_id(rank, make_id, path, timeout=300.0):
     raise TimeoutError("rank %d: no RCCL id at %s after %.0f s" % (rank, path, timeout))
 
 
-def _exchange_blobs(rank, world, blob, prefix, timeout=300.0):
-    """every rank publishes `blob` as <prefix>.<rank> (atomic rename) and reads the others'; returns the list by rank"""
+def _exchange_blobs(rank, world, blob, prefix, timeout=300.0, accept=None):
+    """every rank publishes `blob` as <prefix>.<rank> (atomic rename) and reads the others'; returns the list by rank.
+    accept(data) -> bool: a file that fails it counts as not yet written (a leftover of an earlier attempt under the same name)"""
     tmp = "%s.%d.tmp.%d" % (prefix, rank, os.getpid())
     with open(tmp, "wb") as f:
         f.write(blob)
@@ -160,7 +161,7 @@ def _exchange_blobs(rank, world, blob, prefix, timeout=300.0):
             try:
                 with open("%s.%d" % (prefix, r), "rb") as f:
                     data = f.read()
-                if len(data) == len(blob):
+                if len(data) == len(blob) and (accept is None or accept(data)):
                     out.append(data)
                     break
             except FileNotFoundError:
@@ -208,7 +209,7 @@ class _c_stdout_to_stderr(object):
 class RcclCommunicator(Communicator):
     """GPU ranks over RCCL/xGMI; collectives run on liblghip's compute stream"""
 
-    def __init__(self, rank=None, world_size=None, id_path=None):
+    def __init__(self, rank=None, world_size=None, id_path=None, rendezvous_timeout=300.0, selftest_timeout=60.0):
         from .autograd.hip import lib as L
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
@@ -227,9 +228,12 @@ class RcclCommunicator(Communicator):
         # RCCL prints a version banner on the C-level stdout when a communicator is created; programs that
         # print machine-readable results on stdout (bench.py) must not get it mixed in: send it to stderr
         with _c_stdout_to_stderr():
-            blob = _exchange_unique_id(self.rank, make_id, id_path)
+            blob = _exchange_unique_id(self.rank, make_id, id_path, timeout=rendezvous_timeout)
             L.comm_check(self._lib.lg_comm_init(self.rank, self.world_size, ctypes.create_string_buffer(blob, 128)))
-            self.barrier()          # first collective: whatever RCCL prints lazily also lands on stderr
+            # first collective: on the library's COMMUNICATION stream and awaited by polling an event, so that a collective
+            # that never completes (a peer that did not make it through init) leaves the compute stream usable for the other
+            # forms of the exchange; whatever RCCL prints lazily also lands on stderr
+            L.comm_check(self._lib.lg_comm_selftest(float(selftest_timeout)))
         if self.rank == 0:
             try:
                 os.remove(id_path)
@@ -277,6 +281,8 @@ class RcclCommunicator(Communicator):
         self._L.check(self._L.lib().lg_sync())
 
     def close(self):
+        if getattr(self, "_abandoned", False):
+            return                      # open_communicators dropped this form: a peer did not make it, ncclCommDestroy would wait for it
         self._L.comm_check(self._lib.lg_comm_destroy())
 
 
@@ -290,20 +296,43 @@ class PeerWindowCommunicator(Communicator):
     process, not per device) - which is how the multi-rank device path is tested on one-GPU machines; ranks that share a
     GPU must each run on CUs of their own (`shared_gpu_environment`)."""
     fused_optimizer_exchange = True
+    # Rendezvous files carry the number of the communicator within its job (every rank constructs its communicators in the same
+    # order, so the numbers agree): a second communicator of a job never reads the handle or the "bye" of the first, and the
+    # blob carries the exporter's pid, so a handle left behind by a crashed attempt of a restarted job (same launcher pid and
+    # port under an elastic agent) is told from a live one by `os.kill(pid, 0)`.
+    _generation = 0
 
     def __init__(self, rank=None, world_size=None, id_path=None, capacity_floats=1 << 22, rendezvous_timeout=120.0):
         from .autograd.hip import lib as L
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
         self._L, self._lib = L, L.lib()
-        self._prefix = (_job_rendezvous_path() if id_path is None else id_path) + ".p2p"
+        PeerWindowCommunicator._generation += 1
+        self._prefix = "%s.p2p.%d" % (_job_rendezvous_path() if id_path is None else id_path, PeerWindowCommunicator._generation)
+        self._timeout = rendezvous_timeout
         self._open = False
         handle = ctypes.create_string_buffer(L.P2P_HANDLE_BYTES)
         rc = self._lib.lg_p2p_export(self.rank, self.world_size, int(capacity_floats), handle)
         export_error = None if rc == 0 else self._lib.lg_last_error().decode()
         # a rank that could not export still publishes (64 zero bytes): its peers fail at once instead of waiting for it
-        blobs = _exchange_blobs(self.rank, self.world_size, handle.raw if rc == 0 else bytes(L.P2P_HANDLE_BYTES), self._prefix,
-                                timeout=rendezvous_timeout)
+        pid = ("%-16d" % os.getpid()).encode()
+
+        def exporter_alive(data):
+            try:
+                os.kill(int(data[L.P2P_HANDLE_BYTES:].decode()), 0)
+            except ProcessLookupError:
+                return False                     # the file of an earlier, crashed attempt: wait for the live peer to replace it
+            except (PermissionError, ValueError):
+                pass                             # alive under another user / no pid: let the mapping decide
+            return True
+        try:
+            blobs = _exchange_blobs(self.rank, self.world_size, (handle.raw if rc == 0 else bytes(L.P2P_HANDLE_BYTES)) + pid, self._prefix,
+                                    timeout=rendezvous_timeout, accept=exporter_alive)
+        except TimeoutError:
+            if rc == 0:
+                self._lib.lg_p2p_free()
+            raise
+        blobs = [b[:L.P2P_HANDLE_BYTES] for b in blobs]
         failed = [r for r, b in enumerate(blobs) if not any(b)]
         if failed:
             if rc == 0:
@@ -333,6 +362,21 @@ class PeerWindowCommunicator(Communicator):
         from .autograd.hip.tensor import flush_lazy_readers
         flush_lazy_readers(flat)        # collectives write in place
         return flat
+
+    def failed(self) -> bool:
+        """True once a wait of this communicator gave up and a synchronising call reported it (HipError, LG_ECOMM): every later
+        collective raises, an exchange that did not happen never passes for one that did.  Recovery = close() (which then does
+        not wait for the lost peer) and a new communicator - or a new job: after a lost peer the replicas are out of step."""
+        if not self._open:
+            return False
+        f = ctypes.c_int(0)
+        self._L.check(self._lib.lg_p2p_state(ctypes.byref(f), None))
+        return bool(f.value)
+
+    def memory_kind(self) -> str:
+        kind = ctypes.create_string_buffer(32)
+        self._L.check(self._lib.lg_p2p_state(None, kind))
+        return kind.value.decode()
 
     def allreduce_sum_(self, flat, forked=False):
         self._check_flat(flat)
@@ -365,13 +409,108 @@ class PeerWindowCommunicator(Communicator):
     def close(self):
         if not self._open:
             return
+        lost = self.failed() or getattr(self, "_abandoned", False)     # _abandoned: open_communicators dropped the form, peers may be gone
         self._open = False
-        self.barrier()                                            # every rank has finished its launches
-        self._L.check(self._lib.lg_p2p_disconnect())
-        # nobody maps my window any more once every rank has said so (the files are tiny and stay: a rank that removed its
-        # own could be gone before a slower peer has read it; lightgrad_amd.launch clears the job's directory)
-        _exchange_blobs(self.rank, self.world_size, b"bye", self._prefix + ".bye")
+        if not lost:
+            try:
+                self.barrier()                                    # every rank has finished its launches
+            except self._L.HipError:
+                lost = True                                       # the peer went away between the last step and now
+        try:
+            self._lib.lg_sync()                                   # (a failed communicator's stream may still hold reported launches)
+        finally:
+            self._L.check(self._lib.lg_p2p_disconnect())
+        if not lost:
+            # nobody maps my window any more once every rank has said so (the files carry the communicator's number and are
+            # tiny: a rank that removed its own could be gone before a slower peer has read it; lightgrad_amd.launch clears the
+            # job's directory).  With a lost peer there is nobody to wait for: unmap and free at once.
+            try:
+                _exchange_blobs(self.rank, self.world_size, b"bye", self._prefix + ".bye", timeout=self._timeout)
+            except TimeoutError:
+                pass
         self._L.check(self._lib.lg_p2p_free())
+
+
+# ---- opening the communicators of a job so that no rank is left waiting on a form that does not work ------------------------
+def _run_with_timeout(fn, seconds):
+    """fn() on a helper thread (ctypes calls release the GIL); returns (value, None) or (None, "reason").  A call that does not
+    come back is ABANDONED - its thread stays where it is (daemon) - and the caller goes on without that form."""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:                      # the reason travels to the vote
+            box["error"] = "%s: %s" % (type(e).__name__, (str(e).splitlines() or [""])[0])
+    t = threading.Thread(target=body, daemon=True, name="lightgrad-open-communicator")
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, "no answer within %.0f s (abandoned)" % seconds
+    if "error" in box:
+        return None, box["error"]
+    return box.get("value"), None
+
+
+def _vote(rank, world, name, reason, timeout):
+    """every rank publishes how its attempt at `name` went (None = fine); returns the reasons by rank, alike on every rank"""
+    blob = ("ok" if reason is None else "no: " + reason)[:500].encode("utf-8", "replace").ljust(512)
+    blobs = _exchange_blobs(rank, world, blob, "%s.vote.%s" % (_job_rendezvous_path(), name), timeout=timeout)
+    out = []
+    for b in blobs:
+        text = b.decode("utf-8", "replace").rstrip()
+        out.append(None if text == "ok" else text[4:])
+    return out
+
+
+_vote_round = 0
+
+
+def open_communicators(rank, world, openers, timeout=120.0, vote_timeout=None):
+    """Try the forms of the gradient exchange in the order given and keep those that work on EVERY rank.
+
+        openers   [(name, callable -> Communicator)], e.g. [("rccl", ...), ("peer", ...), ("host", ...)]; a callable may be
+                  None on a rank (the form is then skipped everywhere) and raises or hangs when its form does not work
+        returns   ({name: Communicator}, {name: "why not"}), identical keys on every rank
+
+    Each attempt runs under a timeout on a helper thread, then the ranks VOTE through the job's rendezvous files (no GPU, no
+    collective library involved): a form that failed or did not answer on any rank is dropped by all of them - a rank whose own
+    attempt succeeded closes nothing collectively (the peer may be gone) and simply does not use it.  The first real multi-GPU
+    node a job meets may refuse any of the forms; the job then runs on the next one instead of dying in the first."""
+    global _vote_round
+    vote_timeout = max(2.0 * timeout, 60.0) if vote_timeout is None else vote_timeout
+    opened, why_not = {}, {}
+    for name, opener in openers:
+        _vote_round += 1
+        if opener is None:
+            comm, reason = None, "not attempted on rank %d" % rank
+        else:
+            comm, reason = _run_with_timeout(opener, timeout)
+        reasons = _vote(rank, world, "%d.%s" % (_vote_round, name), reason, vote_timeout)
+        bad = [(r, w) for r, w in enumerate(reasons) if w is not None]
+        if bad:
+            why_not[name] = "; ".join("rank %d: %s" % rw for rw in bad[:3]) + (" (+%d more)" % (len(bad) - 3) if len(bad) > 3 else "")
+            if comm is not None:
+                comm._abandoned = True                      # never close()d collectively: its peers did not make it
+        else:
+            opened[name] = comm
+    return opened, why_not
+
+
+def peer_window_selftest(comm, n=70001):
+    """an all-reduce whose result every rank can compute alone (per-rank seeds): the windows of all ranks carry data"""
+    parts = [np.random.RandomState(4242 + r).uniform(-1, 1, n).astype(np.float32) for r in range(comm.world_size)]
+    want = parts[0].copy()
+    for q in parts[1:]:
+        want = want + q                                      # rank order, fp32: the owner's bits
+    t = HipTensor.from_numpy(parts[comm.rank], requires_grad=False)
+    comm.allreduce_sum_(t)
+    got = t.numpy()
+    if not np.array_equal(got, want):
+        raise AssertionError("peer-window all-reduce self-test: %d of %d values differ (max |diff| %.3g)"
+                             % (int((got != want).sum()), n, float(np.abs(got - want).max())))
+    return comm
 
 
 def shared_gpu_environment(rank: int, world_size: int) -> dict:

@@ -10,7 +10,10 @@ the test box.  Modes:
   bert         one encoder layer of BERT with its fused blocks (attention node, feed-forward node, embedding sum) under DataParallel with
                the peer-window exchange inside the optimizer launch: two steps on per-rank batches; writes rank<r>.npz
   collectives  all-reduce SUM / MAX, broadcast, barrier of the peer-window communicator on awkward sizes, checked in place
-  lost_peer    rank 1 never joins a collective: rank 0 must get HipError (LG_ECOMM) at its next synchronisation, not hang
+  lost_peer    rank 1 never joins a collective: rank 0 must get HipError (LG_ECOMM) at its next synchronisation, not hang;
+               the communicator stays failed (later collectives refused), close() does not wait for the lost peer
+  lost_peer_in_flight   a launch enqueued behind the one that gave up, before any report, is reported too
+  epoch_wrap   exchange counts seeded just below 2^31 and 2^32: the collectives keep working across the wrap
 """
 import argparse
 import os
@@ -247,8 +250,82 @@ def lost_peer(args, rank, world):
         assert "peer-window exchange" in str(e) and "liblghip error -5" in str(e), str(e)
         assert took < 3.0, took
         print("rank 0: lost peer reported after %.2f s: %s" % (took, e))
+    else:
+        raise AssertionError("a collective without its peer returned normally")
+    # the communicator stays failed: a second collective is REFUSED (never launched with waits that fall through) ...
+    assert comm.failed()
+    before = t.numpy().copy()
+    try:
+        comm.allreduce_sum_(t)
+    except L.HipError as e:
+        assert "liblghip error -5" in str(e) and "lost a peer earlier" in str(e), str(e)
+        print("rank 0: second collective refused: %s" % e)
+    else:
+        raise AssertionError("a collective on a failed communicator was launched")
+    HipDevice.synchronize()                        # ... nothing pending, nothing reported twice for the same launch
+    np.testing.assert_array_equal(t.numpy(), before)
+    # ... and close() does not wait for the peer that is gone (no barrier, no "bye")
+    t0 = time.time()
+    comm.close()
+    assert time.time() - t0 < 2.0, time.time() - t0
+    print("rank 0: closed a failed communicator in %.2f s" % (time.time() - t0))
+
+
+def lost_peer_in_flight(args, rank, world):
+    """an exchange recorded in a hipGraph and replayed AFTER the communicator died runs its (short) waits on the dead
+    communicator and is reported again: an exchange that did not happen is never taken for one that did"""
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipDevice, HipGraph, lib as L
+    comm = make_comm("p2p", rank, world)
+    b = HipTensor.from_numpy(np.ones(4096, np.float32), requires_grad=False)
+    graph = HipGraph()
+    with graph.capture():
+        comm.allreduce_sum_(b)
+    graph.replay()                                 # both ranks: works
+    HipDevice.synchronize()
+    np.testing.assert_array_equal(b.numpy(), np.full(4096, float(world), np.float32))
+    if rank != 0:
+        time.sleep(5.0)                            # gone from here on; exits without close()
         return
-    raise AssertionError("a collective without its peer returned normally")
+    errors = []
+    for _ in range(2):                             # first replay: the wait gives up; second: dead communicator, short waits
+        t0 = time.time()
+        graph.replay()
+        try:
+            HipDevice.synchronize()
+        except L.HipError as e:
+            assert "liblghip error -5" in str(e), str(e)
+            errors.append(time.time() - t0)
+    assert len(errors) == 2, errors
+    assert errors[1] < 0.25, errors                # no second LG_P2P_TIMEOUT_MS wait
+    assert comm.failed()
+    print("rank 0: in-flight launch on a dead communicator reported (%s s)" % errors)
+    comm.close()
+
+
+def epoch_wrap(args, rank, world):
+    """exchange counts live modulo 2^32: collectives keep working across 2^31 and across 2^32"""
+    from lightgrad_amd import HipTensor
+    from lightgrad_amd.autograd.hip import HipDevice, lib as L
+    from lightgrad_amd.dist import _exchange_blobs
+    comm = make_comm("p2p", rank, world)
+    lib = L.lib()
+    prefix = os.environ["LIGHTGRAD_RCCL_ID_FILE"] + ".wrap"
+    for k, seed in enumerate((0x7FFFFFFF - 3, -3)):
+        HipDevice.synchronize()
+        _exchange_blobs(rank, world, b"idle", "%s.a%d" % (prefix, k), timeout=60)      # nobody has a launch in flight
+        L.check(lib.lg_p2p_debug_seed_epochs(seed))
+        _exchange_blobs(rank, world, b"seeded", "%s.b%d" % (prefix, k), timeout=60)    # nobody launches before everyone has seeded
+        for it in range(8):                                                             # crosses the wrap at the 4th / 3rd exchange
+            parts = [np.random.RandomState(31 * it + r).uniform(-1, 1, 5000).astype(np.float32) for r in range(world)]
+            want = parts[0].copy()
+            for q in parts[1:]:
+                want = want + q
+            t = HipTensor.from_numpy(parts[rank], requires_grad=False)
+            comm.allreduce_sum_(t)
+            np.testing.assert_array_equal(t.numpy(), want, err_msg="seed %d exchange %d" % (seed, it))
+    comm.close()
+    print("rank %d: epochs wrapped" % rank)
 
 
 if __name__ == "__main__":
@@ -266,7 +343,8 @@ if __name__ == "__main__":
     a.overlap, a.fused, a.graph = bool(a.overlap), bool(a.fused), bool(a.graph)
     a.dims = tuple(int(v) for v in a.dims.split(","))
     try:
-        {"train": train, "bert": bert_train, "collectives": collectives, "lost_peer": lost_peer}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
+        {"train": train, "bert": bert_train, "collectives": collectives, "lost_peer": lost_peer, "lost_peer_in_flight": lost_peer_in_flight,
+         "epoch_wrap": epoch_wrap}[a.mode](a, int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]))
     except BaseException:
         import traceback
         traceback.print_exc()

@@ -160,6 +160,70 @@ def test_a_lost_peer_is_an_error_not_a_hang(spawn_ranks, tmp_path):
     assert "lost peer reported" in res["outputs"][0], res["outputs"][0]
 
 
+def test_launches_in_flight_on_a_dead_communicator_are_reported_too(spawn_ranks, tmp_path):
+    res = _run(spawn_ranks, tmp_path, "--mode", "lost_peer_in_flight", env={"LG_P2P_TIMEOUT_MS": "300"}, wait_for_all=True, timeout=120)
+    assert "in-flight launch on a dead communicator reported" in res["outputs"][0], res["outputs"][0]
+
+
+def test_exchange_counts_wrap_around(spawn_ranks, tmp_path):
+    res = _run(spawn_ranks, tmp_path, "--mode", "epoch_wrap", timeout=180)
+    assert all("epochs wrapped" in o for o in res["outputs"]), res["outputs"]
+
+
+# ---- bench.py itself with two ranks on the one GPU (the multi-rank bench under the driver's pytest) ---------------
+def _bench_line(output):
+    import json
+    lines = [l for l in output.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, "expected one JSON line from rank 0, got %d:\n%s" % (len(lines), output[-4000:])
+    return json.loads(lines[0])
+
+
+BENCH = ["bench.py", "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "40", "--warmup", "5", "--no-extras"]
+
+
+def test_bench_two_ranks_end_to_end(spawn_ranks):
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: communicators, forms of the exchange, calibration, the JSON line"""
+    res = spawn_ranks(2, BENCH, timeout=420)
+    assert res["rc"] == 0, "\n---- next rank ----\n".join(res["outputs"])
+    out = _bench_line(res["outputs"][0])
+    assert out["n_gpus"] == 2 and out["steps"] == 40 and out["metric"].startswith("REHEARSAL_")
+    ranks = out["ranks"]
+    assert ranks["communicator_ranks"] == 2 and ranks["world_size"] == 2
+    assert ranks["exchange_form"] in ("p2p", "graph-inline", "eager")
+    assert ranks["communicator"] == "PeerWindowCommunicator" and ranks["communicator_fallback"] is None
+    assert ranks["peer_window_memory"] in ("uncached", "fine-grained", "hipMalloc")
+    assert np.isfinite(out["final_loss"]) and out["value"] > 0
+    assert len(ranks["per_rank_steps_per_sec"]) == 2
+    pre = ranks["preflight"]
+    assert pre["devices_visible"] >= 1 and pre["can_access_peer"][0][0] == 1
+    cost = ranks["exchange_us_per_step"]
+    assert cost["form"] == ranks["exchange_form"] and cost["with_exchange_us"] > 0 and cost["without_exchange_us"] > 0
+    cal = ranks["exchange_calibration_steps_per_sec"]
+    assert isinstance(cal["eager"], float) and isinstance(cal["p2p"], float), cal
+
+
+def test_bench_falls_back_when_rccl_does_not_come_up(spawn_ranks):
+    """RCCL initialisation fails on rank 1 and never returns on rank 0 (what ncclCommInitRank does when a peer falls out):
+    every rank drops RCCL after --comm-open-timeout and the job runs on the peer windows; the line says so"""
+    res = spawn_ranks(2, BENCH + ["--comm-open-timeout", "4"], env={"LG_BENCH_FAIL_RCCL": "init:1"}, timeout=420)
+    assert res["rc"] == 0, "\n---- next rank ----\n".join(res["outputs"])
+    out = _bench_line(res["outputs"][0])
+    ranks = out["ranks"]
+    assert ranks["communicator"] == "PeerWindowCommunicator" and ranks["communicator_ranks"] == 2
+    assert "RCCL not usable" in ranks["communicator_fallback"] and "simulated RCCL initialisation failure" in ranks["communicator_fallback"]
+    assert "rank 0: no answer within 4 s" in ranks["communicators_not_usable"]["rccl"]
+    assert ranks["exchange_form"] in ("p2p", "graph-inline", "eager") and np.isfinite(out["final_loss"]) and out["value"] > 0
+
+
+def test_bench_watchdog_ends_a_stuck_form_with_the_line_in_hand(spawn_ranks):
+    res = spawn_ranks(2, BENCH + ["--exchange-timeout", "15"], env={"LG_BENCH_SIMULATE_HANG": "p2p"}, timeout=420, wait_for_all=True)
+    assert res["codes"] == [3, 3], (res["codes"], "\n---- next rank ----\n".join(res["outputs"]))
+    out = _bench_line(res["outputs"][0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["ranks"]["exchange_form"] == "eager"
+    assert "no answer within 15 s" in out["ranks"]["exchange_calibration_steps_per_sec"]["p2p"]
+    assert out["ranks"]["in_graph_exchange_fallback"] == "p2p: watchdog"
+
+
 def test_two_ranks_bert_layer_with_fused_blocks(spawn_ranks, tmp_path):
     """BASELINE configs 4 + 5 together: an encoder layer of BERT (self-attention node, feed-forward node, embedding sum, LayerNorms,
     masked-LM cross-entropy) data parallel over two rank processes, the gradient exchange inside the multi-tensor optimizer

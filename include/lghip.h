@@ -308,6 +308,29 @@ int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* v, int nseg
                           double lr, double b1, double b2, double eps,
                           int64_t* step, int64_t step_slots, double gscale, int belief);
 
+/* The update applied by the kernel that MAKES the gradient (round 4): `p += compute_delta(p.grad, i)` of optim.py:10-13 / :47-52
+ * without a launch of its own.  The reference's optimizer is ~14 tensor expressions per parameter after backward; the fused
+ * kernels above made that one launch; these entry points let the backward kernels themselves apply it to the values they are
+ * about to store - GEMM epilogues (lg_gemm_f32 / lg_gemm_rowsum_f32 / lg_gemm_fused_f32 on the small tiles: C and the row
+ * sums) and lg_head_bwd_f32 (dW, db).  Same arithmetic per element as lg_adam_multi_dev_f32, so the same bits.
+ *   lg_adam_plan_create     one parameter's update, p_in -> p_out (p_out != p_in: other workgroups of the producing launch
+ *                           still read the old values, e.g. dx = g @ W next to dW = g^T @ x), moments m, v in place, the
+ *                           step number read from step_in[0] (t = step_in[0] * t_mul + t_add) and, for ONE plan of an
+ *                           optimizer, written as step_out[0] = step_in[0] + 1 (step_out NULL elsewhere; step_out !=
+ *                           step_in: an optimizer keeps two plans per parameter, A -> B and B -> A, and alternates).
+ *   lg_adam_epilogue_arm    before backward: the next kernel that OVERWRITES `grad` (n floats, dense; beta = 0) applies the
+ *                           plan; the gradient itself is still written.  A kernel that ADDS into `grad` after that is
+ *                           refused (LG_EINVAL): for gradients made by ONE kernel per step.
+ *   lg_adam_epilogue_finish after backward: applies the armed plans no kernel took, in one launch (none when all were
+ *                           taken), and disarms everything.  Host bookkeeping only: a step recorded in a hipGraph replays
+ *                           as recorded; the directions alternate, so a graph holds an EVEN number of steps. */
+int lg_adam_plan_create(void** plan, const float* p_in, float* p_out, float* m, float* v, int64_t n,
+                        const int64_t* step_in, int64_t* step_out, int64_t t_mul, int64_t t_add,
+                        double lr, double b1, double b2, double eps, double gscale, int belief);
+int lg_adam_plan_destroy(void* plan);
+int lg_adam_epilogue_arm(const float* grad, int64_t n, const void* plan);
+int lg_adam_epilogue_finish(int* applied_by_kernels, int* applied_here);
+
 /* ---- fused loss ----------------------------------------
  * loss.mse forward (loss.py:4-10) for dense fp32 tensors of n elements:
  *   err[i] = y[i] + (-y_hat[i]);   loss[0] = (sum_i err[i]^2 * (1/n)) * 0.5

@@ -23,6 +23,9 @@ from . import lib as _l
 class HipGraph(object):
 
     capturing = False         # True inside a `capture()` block (kernels are being recorded, not executed)
+    # callables run when a capture ends successfully (before the graph is instantiated): state that alternates per step on the
+    # host - tensor.BackwardUpdate's two parameter buckets - checks that the recorded steps bring it back to where it started
+    capture_end_hooks = []
 
     def __init__(self):
         self._exec = None
@@ -45,6 +48,12 @@ class HipGraph(object):
         HipGraph.capturing = False
         _l.check(L.lg_graph_end(ctypes.byref(handle)))
         self._exec = handle
+        try:
+            for hook in list(HipGraph.capture_end_hooks):
+                hook()
+        except BaseException:
+            self.destroy()
+            raise
 
     def replay(self):
         assert self._exec is not None, "nothing captured"

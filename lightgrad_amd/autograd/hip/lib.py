@@ -81,6 +81,11 @@ PROTOTYPES = {
     "lg_counter_add_i64": (c_int, [c_void_p, c_int64]),
     "lg_adam_multi_dev_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, _I64P, c_double, c_double, c_double,
                                       c_double, c_void_p, c_int64, c_double, c_int]),
+    "lg_adam_plan_create": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                    c_double, c_double, c_double, c_double, c_double, c_int]),
+    "lg_adam_plan_destroy": (c_int, [c_void_p]),
+    "lg_adam_epilogue_arm": (c_int, [c_void_p, c_int64, c_void_p]),
+    "lg_adam_epilogue_finish": (c_int, [POINTER(c_int), POINTER(c_int)]),
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_gemm_addend_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

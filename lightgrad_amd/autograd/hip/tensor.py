@@ -154,6 +154,102 @@ def _make_lazy_readers_real(t) -> None:
                 reader._materialize()
 
 
+class BackwardUpdate(object):
+    """The optimizer's update applied by the kernels that MAKE the gradients (include/lghip.h: lg_adam_plan_* /
+    lg_adam_epilogue_*): the weight-gradient GEMM's epilogue, its row-sum column (bias gradients), the slab workgroups of the
+    skinny-head backward.  The optimizer's own launch disappears from the step (MNIST MLP: 5 launches -> 4).
+
+    The new parameter values cannot overwrite the old ones - `dx = g @ W` runs in the same launch as `dW = g^T @ x` - so the
+    parameters live in TWO flat buckets and every step reads one and writes the other; the parameter tensors are re-pointed
+    after each step (views handed out earlier keep the old values: take them per step, as the tape does).  The step number
+    behind the bias corrections alternates between two device words the same way.  A hipGraph must therefore record an EVEN
+    number of steps.  Gradients any other kernel produces (or that are added to, not overwritten) are applied by
+    `finish()` in one extra launch - the result is the same either way, bit for bit: the same per-element arithmetic."""
+
+    def __init__(self, flat_p, parameters, grad, m, v, offsets, lr, b1, b2, eps, grad_scale, belief, steps_done):
+        lib = _l.lib()
+        self.parameters, self.grad, self.offsets = tuple(parameters), grad, tuple(offsets)
+        self.buckets = (flat_p, HipTensor.empty(flat_p._shape, requires_grad=False))
+        self.m, self.v = m, v
+        self.steps = HipTensor.from_numpy(np.asarray([steps_done, steps_done], dtype=np.int64), requires_grad=False)
+        self.parity, self.armed, self._captured_steps = 0, False, 0
+        self.plans = ([], [])
+        n_params = len(self.parameters)
+        for direction in (0, 1):
+            src, dst = self.buckets[direction], self.buckets[1 - direction]
+            for i, (a, b) in enumerate(zip(self.offsets[:-1], self.offsets[1:])):
+                if b == a:
+                    self.plans[direction].append(None)
+                    continue
+                plan = ctypes.c_void_p()
+                _l.check(lib.lg_adam_plan_create(ctypes.byref(plan), src.ptr + 4 * a, dst.ptr + 4 * a, m.ptr + 4 * a, v.ptr + 4 * a, b - a,
+                                                 self.steps.ptr + 8 * direction,
+                                                 (self.steps.ptr + 8 * (1 - direction)) if i == self._first_nonempty() else None,
+                                                 n_params, i + 1, lr, b1, b2, eps, grad_scale, 1 if belief else 0))
+                self.plans[direction].append(plan.value)
+
+        import weakref
+        from .graph import HipGraph
+        me = weakref.ref(self)
+
+        def capture_ended():
+            this = me()
+            if this is None:
+                HipGraph.capture_end_hooks.remove(capture_ended)
+                return
+            recorded, this._captured_steps = this._captured_steps, 0
+            if recorded % 2:
+                for _ in range(1):                    # undo the host-side flip the recorded (not executed) odd step left behind
+                    this.parity ^= 1
+                    for p in this.parameters:
+                        p._data = this.buckets[this.parity]._data
+                raise RuntimeError("a hipGraph recorded %d steps of an optimizer whose update rides in the backward kernels: its two "
+                                   "parameter buckets alternate, record an EVEN number of steps per graph" % recorded)
+        HipGraph.capture_end_hooks.append(capture_ended)
+
+    def _first_nonempty(self) -> int:
+        return next(i for i, (a, b) in enumerate(zip(self.offsets[:-1], self.offsets[1:])) if b > a)
+
+    def arm(self) -> None:
+        """before backward (optimizer.zero_grad): the kernels that overwrite a parameter's gradient apply its update"""
+        if self.armed:
+            raise RuntimeError("the optimizer's update rides in the backward kernels: zero_grad() must be followed by backward() and "
+                               "step() before the next zero_grad()")
+        flush_lazy_readers(self.buckets[1 - self.parity])      # anything still waiting to read the bucket about to be overwritten
+        lib = _l.lib()
+        for plan, a, b in zip(self.plans[self.parity], self.offsets[:-1], self.offsets[1:]):
+            if plan is not None:
+                _l.check(lib.lg_adam_epilogue_arm(self.grad.ptr + 4 * a, b - a, plan))
+        self.armed = True
+
+    def finish(self) -> tuple:
+        """after backward (optimizer.step): apply what no kernel took, re-point the parameters at the bucket just written.
+        Returns (updates applied by backward kernels, updates applied here)."""
+        assert self.armed, "optimizer.step() without zero_grad() + backward() before it"
+        taken, here = ctypes.c_int(0), ctypes.c_int(0)
+        _l.check(_l.lib().lg_adam_epilogue_finish(ctypes.byref(taken), ctypes.byref(here)))
+        from .graph import HipGraph
+        if HipGraph.capturing:
+            self._captured_steps += 1
+        self.armed = False
+        self.parity ^= 1
+        now = self.buckets[self.parity]._data
+        for p in self.parameters:
+            p._data = now
+        return taken.value, here.value
+
+    def current_bucket(self):
+        return self.buckets[self.parity]
+
+    def __del__(self):
+        if _l._lib is None:
+            return
+        for direction in (0, 1):
+            for plan in self.plans[direction]:
+                if plan is not None:
+                    _l._lib.lg_adam_plan_destroy(plan)
+
+
 class HipDevice(object):
     """The GPU this process is bound to (one process per GPU; reference analog: OpenCLDevice,
     opencl/device.py:68-115 - context + in-order queue + memory pool)."""
@@ -511,6 +607,14 @@ class HipTensor(AbstractTensor):
         _l.check(_l.lib().lg_p2p_adam_multi_dev_f32(self.ptr, grad.ptr, m.ptr, v.ptr, len(offsets) - 1, _l.i64(tuple(offsets)),
                                                     lr, b1, b2, eps, step_counter.ptr, step_counter.numel() - 2, grad_scale,
                                                     1 if belief else 0))
+
+    def _new_backward_update(self, parameters, grad, m, v, offsets, lr, b1, b2, eps, grad_scale, belief, steps_done=0):
+        """optional optimizer hook (optim.Adam.fuse_update_into_backward): self/grad/m/v are flat buckets; returns the object
+        that arms / finishes the update-in-the-backward-kernels of every step (BackwardUpdate)"""
+        for t in (self, grad, m, v):
+            assert t.is_contiguous() and t._shape == self._shape and t._dtype == np.float32
+        assert offsets[-1] == self.numel()
+        return BackwardUpdate(self, parameters, grad, m, v, offsets, lr, b1, b2, eps, grad_scale, belief, steps_done)
 
     @staticmethod
     def _new_step_counter(step: int, slots: int = 0) -> "HipTensor":

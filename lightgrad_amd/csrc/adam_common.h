@@ -28,4 +28,52 @@ inline AdamScalars adam_scalars(double lr, double b1, double b2, double eps, dou
     return c;
 }
 
+// ---- the update applied where the gradient is made (lg_adam_plan_* / lg_adam_epilogue_*, optim.hip) --------------------
+// One parameter's update as data in DEVICE memory: the kernel that produces the parameter's gradient (GEMM epilogue of
+// gemm_tile_body.inc, the slab workgroups of head.hip) applies it to the values it is about to store, so the optimizer's own
+// launch disappears from the step.  The new parameter values go to a SECOND buffer (p_out != p_in): other workgroups of the
+// same launch still read the old ones (dx = g @ W next to dW = g^T @ x in sgemm_pair_wgrad_xgrad; the dx tiles next to the
+// dW slabs in head_bwd).  The step number behind the bias corrections alternates between two words the same way: every
+// workgroup reads step_in, which nobody writes during this step, and exactly one workgroup per step - the one that handles
+// element 0 of the plan whose step_out is not NULL - writes step_out = step_in + 1.
+struct AdamPlan {
+    const float*   p_in;
+    float*         p_out;
+    float*         m;
+    float*         v;
+    const int64_t* step_in;     // optimizer steps done so far
+    int64_t*       step_out;    // NULL except in the one plan of the optimizer that advances the step number
+    int64_t        n;           // elements
+    int64_t        t_mul, t_add;   // t = steps_done * t_mul + t_add (the reference advances t once per PARAMETER, optim.py:36/:48)
+    double         b1, b2;
+    AdamScalars    c;           // inv_bias1 / inv_bias2 are filled in on the device
+};
+
+// the scalars of this step for one wavefront: lane 0 reads the step number and forms the two double-precision powers
+// (as the python expression does), every lane receives them - no LDS, no workgroup barrier, callable where only some waves
+// of a workgroup are still alive
+__device__ __forceinline__ AdamScalars adam_plan_scalars(const AdamPlan* pl, int64_t& steps_done) {
+    AdamScalars c = pl->c;
+    float i1 = 0.f, i2 = 0.f;
+    long long done = 0;
+    if ((threadIdx.x & 63) == 0) {
+        done = __hip_atomic_load(pl->step_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double t = double(done * pl->t_mul + pl->t_add);
+        i1 = float(1.0 / (1.0 - pow(pl->b1, t)));
+        i2 = float(1.0 / (1.0 - pow(pl->b2, t)));
+    }
+    c.inv_bias1 = __shfl(i1, 0, 64);
+    c.inv_bias2 = __shfl(i2, 0, 64);
+    steps_done = (long long)(__shfl((unsigned long long)done, 0, 64));
+    return c;
+}
+
+// host side (optim.hip): the plan armed for the gradient buffer `grad` of `n` floats, if the launch being prepared may apply
+// it - i.e. it OVERWRITES the gradient (accumulate == 0: the first and only write of this step).  The plan then counts as
+// applied.  NULL: nothing armed, or not applicable (the optimizer's lg_adam_epilogue_finish applies what is left).
+// A launch that ADDS into a gradient whose plan was already applied in this step is an error: *rc = LG_EINVAL.
+const AdamPlan* adam_epilogue_take(const void* grad, int64_t n, int accumulate, int* rc);
+// a launch that only adds into / reads gradients: fails when `grad` belongs to a plan already applied in this step
+int adam_epilogue_check_write(const void* grad);
+
 }  // namespace lg

@@ -28,6 +28,7 @@
 // pad-to-128 and contiguous() copies (opencl/kernels.py:201-337) is not reproduced.
 #include "common.h"
 #include "gelu_common.h"
+#include "adam_common.h"
 #include "tail_jobs.h"
 #include <cstdlib>
 #include <type_traits>
@@ -108,6 +109,10 @@ struct GemmArgs {
     // dx = [g0 | g1 | g2] @ [W0; W1; W2]): every seg_steps K-steps the running B pointer jumps to the next operand
     int     seg_k, seg_steps;
     int64_t seg_jump[2];
+    // the optimizer's update of the parameter whose gradient this product is, applied in the epilogue (lg_adam_epilogue_arm;
+    // small tiles, one K-group): adam_c for C (dense, ldc == N), adam_r for the row sums.  Device pointers, NULL almost always.
+    const AdamPlan* adam_c;
+    const AdamPlan* adam_r;
 #ifdef LG_GEMM_TIMELINE
     // experiments build only (make timeline; tools/gemm_timeline.py): 8 timestamps of the 100 MHz wall clock per workgroup
     unsigned long long* tl;
@@ -133,6 +138,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // the fold out of that instantiation keeps its main loop free of spills
 template <int BM, int BN> constexpr bool kHasExtras = BM * BN < 256 * 256;      // relu operands, row sums: small tiles only
 template <int BM, int BN, int KG = 1> constexpr bool kCanSplitK = kHasExtras<BM, BN> && KG == 1;
+// the optimizer's update in the epilogue (lg_adam_epilogue_arm): tiles up to 128x128 with one K-group
+template <int BM, int BN, int KG = 1> constexpr bool kCanAdam = BM * BN <= 128 * 128 && KG == 1;
 
 // KG = 2: "K-groups" - the split of K happens INSIDE the workgroup.  Twice the waves on the same BM x BN tile; a K-step stages
 // BK*KG k-values, wave group g multiplies k in [g*BK, (g+1)*BK) of it, and after the loop group 1 hands its accumulators to
@@ -440,6 +447,7 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
     if (G.active != 1 || pair_state().active) return false;
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n;
     if (akc || bkc || !va || !vb || batch != 1 || tiles > kGroupTiles || g.relu_a || g.relu_b || g.multi || g.seg_k) return false;
+    if (g.adam_c || g.adam_r) return false;              // (the group's argument block does not carry optimizer plans)
     bool clash = false;
     for (int i = 0; i < G.count; ++i)
         clash = clash || G.queued[i].C == g.C || (g.rowsum && G.queued[i].rowsum == g.rowsum);
@@ -640,7 +648,19 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
         g.seg_k = extras->seg_k;
         g.seg_jump[0] = extras->seg_jump[0]; g.seg_jump[1] = extras->seg_jump[1];
     }
-    const bool fused_extras = rowsum != nullptr || relu_a || relu_b || act != 0 || g.multi || g.seg_k;     // not compiled into the 256x256 tile
+    // the optimizer's update in this launch's epilogue: a single product that OVERWRITES an armed gradient (optim.hip)
+    {
+        int arc = LG_OK;
+        const bool plain = batch == 1 && ldc == N && bias == nullptr && addend == nullptr && act == 0 && !g.multi && !g.seg_k;
+        g.adam_c = adam_epilogue_take(C, M * N, plain ? accumulate : 1, &arc);
+        if (arc != LG_OK) return arc;
+        if (rowsum) {
+            g.adam_r = adam_epilogue_take(rowsum, M, plain ? rowsum_accumulate : 1, &arc);
+            if (arc != LG_OK) return arc;
+        }
+    }
+    const bool has_adam = g.adam_c != nullptr || g.adam_r != nullptr;
+    const bool fused_extras = rowsum != nullptr || relu_a || relu_b || act != 0 || g.multi || g.seg_k || has_adam;     // not compiled into the 256x256 tile
     LG_ARG(!(relu_a || relu_b) || batch == 1, "lg_gemm_fused_f32: one matrix product");
     static const char* group_env = getenv("LG_GEMM_GROUP");
     g.group_m = group_env ? atoi(group_env) : 8;
@@ -689,7 +709,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
             static const char* pair_kg_env = getenv("LG_GEMM_PAIR_KG");
             const bool keep_for_pair = (lg::pair_state().active == 1 && !(pair_kg_env && atoi(pair_kg_env) == 1))
                                        || (lg::group_state().active == 1 && !akc && !bkc && nblocks(64, 64) <= lg::kGroupTiles);
-            if (tile == 9 && batch == 1 && !keep_for_pair) {
+            if (tile == 9 && batch == 1 && !keep_for_pair && !has_adam) {
                 // Too few 64x64 tiles to fill the chip: split K across workgroups (slabs + ticket + fold) or INSIDE a workgroup
                 // on a half-size tile (64x32 / 32x64 with two K-groups, one LDS exchange)?  Same model as launch_config (us):
                 // K-steps x time per step (+ hand-off), constants from tools/gemm_timeline.py - a K-group step stages 64 k and
@@ -711,6 +731,7 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 if (tk <= cus && kgroups + 0.5 < best64) tile = t7 <= t8 ? 7 : 8;
             }
         }
+        if (has_adam && (tile == 1 || tile == 2 || tile == 7 || tile == 8)) tile = 9;       // (forced by LG_GEMM_TILE: kCanAdam tiles only)
         switch (tile) {
             case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
             case 2:

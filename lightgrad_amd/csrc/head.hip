@@ -23,6 +23,7 @@
 // bit-reproducible from run to run.  Everything elementwise (bias add, err, the relu mask) rounds once per operation
 // like the tape's ops.
 #include "common.h"
+#include "adam_common.h"
 #include <cstdlib>
 
 namespace lg {
@@ -124,6 +125,10 @@ struct HeadBwd {
     int          n_tiles;
     int          col_blocks;   // dx tiles per row of tiles
     int          g_dense;      // outs == OMAX and g 16-byte aligned: g is staged with float4 copies
+    // the optimizer's update of W / b applied by the slab workgroups to the gradient values they are about to store
+    // (lg_adam_epilogue_arm, optim.hip); the new W goes to the plan's second buffer - the dx tiles of this launch read the old one
+    const AdamPlan* adam_w;
+    const AdamPlan* adam_b;
 };
 
 constexpr int kHeadThreads = 1024;                 // 16 wavefronts: a slab workgroup has a CU to itself
@@ -215,21 +220,45 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
             }
         }
         __syncthreads();
-        if (tid < OMAX * (kSlabCols + 1)) {
-            const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
-            if (j < a.outs && (c < kSlabCols || slab == 0)) {
-                float s = 0.f;
+        static_assert(OMAX * (kSlabCols + 1) <= 192, "the writers below are the first three wavefronts");
+        if (tid < 192) {
+            // (whole wavefronts enter: the step's scalars are formed by lane 0 and handed to the others)
+            AdamScalars cw, cb;
+            int64_t done_w = 0, done_b = 0;
+            if (a.adam_w) cw = adam_plan_scalars(a.adam_w, done_w);
+            if (a.adam_b && slab == 0) cb = adam_plan_scalars(a.adam_b, done_b);
+            if (tid < OMAX * (kSlabCols + 1)) {
+                const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
+                if (j < a.outs && (c < kSlabCols || slab == 0)) {
+                    float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += red[(w * OMAX + j) * (kSlabCols + 1) + c];
-                if (c < kSlabCols) {
-                    const int kk = slab * kSlabCols + c;
-                    if (a.dw && kk < a.hidden) {
-                        float* d = a.dw + int64_t(j) * a.hidden + kk;
-                        *d = a.dw_accumulate ? *d + s : s;
+                    for (int w = 0; w < NW; ++w) s += red[(w * OMAX + j) * (kSlabCols + 1) + c];
+                    if (c < kSlabCols) {
+                        const int kk = slab * kSlabCols + c;
+                        if (a.dw && kk < a.hidden) {
+                            const int64_t idx = int64_t(j) * a.hidden + kk;
+                            const float gv = a.dw_accumulate ? a.dw[idx] + s : s;
+                            a.dw[idx] = gv;
+                            if (a.adam_w) {
+                                float P = a.adam_w->p_in[idx], M = a.adam_w->m[idx], V = a.adam_w->v[idx];
+                                adam_elem(P, gv, M, V, cw);
+                                a.adam_w->p_out[idx] = P; a.adam_w->m[idx] = M; a.adam_w->v[idx] = V;
+                            }
+                        }
+                    } else if (a.db) {
+                        const float gv = a.db_accumulate ? a.db[j] + s : s;
+                        a.db[j] = gv;
+                        if (a.adam_b) {
+                            float P = a.adam_b->p_in[j], M = a.adam_b->m[j], V = a.adam_b->v[j];
+                            adam_elem(P, gv, M, V, cb);
+                            a.adam_b->p_out[j] = P; a.adam_b->m[j] = M; a.adam_b->v[j] = V;
+                        }
                     }
-                } else if (a.db) {
-                    a.db[j] = a.db_accumulate ? a.db[j] + s : s;
                 }
+            }
+            if (tid == 0 && slab == 0) {              // the one workgroup per step that advances the optimizer's step number
+                if (a.adam_w && a.adam_w->step_out) __hip_atomic_store(a.adam_w->step_out, done_w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.adam_b && a.adam_b->step_out) __hip_atomic_store(a.adam_b->step_out, done_b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         return;
@@ -343,6 +372,11 @@ extern "C" int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const floa
     a.n_tiles = int(tiles);
     const int omax = outs <= 4 ? 4 : (outs <= 8 ? 8 : (outs <= 10 ? 10 : 16));
     a.g_dense = (omax == outs && aligned16(g)) ? 1 : 0;
+    {
+        int arc = LG_OK;
+        if (dw) { a.adam_w = adam_epilogue_take(dw, outs * hidden, dw_accumulate, &arc); if (arc != LG_OK) return arc; }
+        if (db) { a.adam_b = adam_epilogue_take(db, outs, db_accumulate, &arc); if (arc != LG_OK) return arc; }
+    }
     hipStream_t s = rt().stream;
     if (omax == 4)        hipLaunchKernelGGL(head_bwd<4>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);
     else if (omax == 8)   hipLaunchKernelGGL(head_bwd<8>, dim3(unsigned(grid)), dim3(kHeadThreads), 0, s, a);

@@ -9,6 +9,7 @@
 // (the tape's `/` is `a * b**-1`, autograd/ops.py:30-36, hence the reciprocal-then-multiply form)
 #include "common.h"
 #include "adam_common.h"
+#include <vector>
 
 namespace lg {
 
@@ -245,5 +246,151 @@ extern "C" int lg_adam_multi_dev_f32(float* p, const float* g, float* m, float* 
         if (rc != LG_OK) return rc;
         slot_base += used;
     }
+    return LG_OK;
+}
+
+// ---- the update applied where the gradient is made ---------------------------------------------------------------------
+// Round 4: the MLP step spent 6 of its 60 us in the optimizer's own launch, which only re-reads what
+// the backward kernels have just written.  An optimizer can instead describe every parameter's update once
+// (lg_adam_plan_create: two plans per parameter, one per direction between its two value buffers), ARM the plans of the
+// coming step for the gradient buffers they belong to (lg_adam_epilogue_arm, in zero_grad) and let the kernels that write
+// those gradients apply them (adam_epilogue_take: GEMM epilogues incl. the row-sum column, head_bwd's slab workgroups).
+// lg_adam_epilogue_finish applies whatever no kernel took (one launch for all of them; none when every plan was taken)
+// and ends the step.  Everything is host bookkeeping + fixed device pointers: a step recorded in a hipGraph replays as is;
+// the two directions alternate, so a graph must hold an EVEN number of steps.
+namespace lg {
+
+struct ArmedPlan {
+    const void*     grad;
+    const AdamPlan* plan_dev;
+    int64_t         n;
+    bool            applied;
+};
+struct EpilogueState {
+    std::vector<ArmedPlan> armed;
+};
+static EpilogueState& epi() { static EpilogueState s; return s; }
+
+const AdamPlan* adam_epilogue_take(const void* grad, int64_t n, int accumulate, int* rc) {
+    if (rc) *rc = LG_OK;
+    EpilogueState& E = epi();
+    if (E.armed.empty() || grad == nullptr) return nullptr;
+    for (ArmedPlan& a : E.armed) {
+        if (a.grad != grad) continue;
+        if (a.applied) {
+            set_error("a kernel writes the gradient at %p again after its optimizer update was applied by the kernel that wrote it "
+                      "first in this step (lg_adam_epilogue_arm is for gradients written by ONE kernel per step: no shared weights)", grad);
+            if (rc) *rc = LG_EINVAL;
+            return nullptr;
+        }
+        if (accumulate || a.n != n) return nullptr;      // adds to an existing gradient / another extent: left to lg_adam_epilogue_finish
+        a.applied = true;
+        return a.plan_dev;
+    }
+    return nullptr;
+}
+
+int adam_epilogue_check_write(const void* grad) {
+    int rc = LG_OK;
+    for (const ArmedPlan& a : epi().armed)
+        if (a.grad == grad && a.applied) { (void)adam_epilogue_take(grad, a.n, 1, &rc); break; }
+    return rc;
+}
+
+constexpr int kPlanBatch = 32;
+struct PlanBatch {
+    const AdamPlan* plan[kPlanBatch];
+    const float*    grad[kPlanBatch];
+    int             count;
+};
+
+// the plans no kernel took: blockIdx.y = plan, the update of adam_multi_dev with p_in -> p_out
+__global__ void __launch_bounds__(256) adam_plan_apply(PlanBatch pb) {
+    const AdamPlan* pl = pb.plan[blockIdx.y];
+    const float* __restrict__ g = pb.grad[blockIdx.y];
+    const int64_t n = pl->n;
+    const int64_t first = int64_t(blockIdx.x) * blockDim.x;
+    if (first >= n) return;
+    int64_t steps_done;
+    const AdamScalars c = adam_plan_scalars(pl, steps_done);
+    const float* __restrict__ pin = pl->p_in;
+    float* __restrict__ pout = pl->p_out;
+    float* __restrict__ m = pl->m;
+    float* __restrict__ v = pl->v;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = first + threadIdx.x; i < n; i += stride) {
+        float P = pin[i], M = m[i], V = v[i];
+        adam_elem(P, g[i], M, V, c);
+        pout[i] = P; m[i] = M; v[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pl->step_out) __hip_atomic_store(pl->step_out, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace lg
+
+extern "C" int lg_adam_plan_create(void** plan, const float* p_in, float* p_out, float* m, float* v, int64_t n,
+                                   const int64_t* step_in, int64_t* step_out, int64_t t_mul, int64_t t_add,
+                                   double lr, double b1, double b2, double eps, double gscale, int belief) {
+    LG_REQUIRE_INIT();
+    LG_ARG(plan && p_in && p_out && m && v && step_in && n >= 1, "lg_adam_plan_create: NULL pointer or empty parameter");
+    LG_ARG(p_in != p_out, "lg_adam_plan_create: the new values need a buffer of their own (p_out != p_in): kernels of the same launch still read the old ones");
+    LG_ARG(!capturing(), "lg_adam_plan_create: not while capturing a graph (create the plans first)");
+    AdamPlan h;
+    memset(&h, 0, sizeof(h));
+    h.p_in = p_in; h.p_out = p_out; h.m = m; h.v = v; h.step_in = step_in; h.step_out = step_out; h.n = n;
+    h.t_mul = t_mul; h.t_add = t_add; h.b1 = b1; h.b2 = b2;
+    h.c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
+    void* d = nullptr;
+    int rc = lg_malloc(&d, sizeof(AdamPlan));
+    if (rc != LG_OK) return rc;
+    LG_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, rt().stream));
+    LG_HIP(hipStreamSynchronize(rt().stream));          // `h` lives on this stack frame
+    *plan = d;
+    return LG_OK;
+}
+
+extern "C" int lg_adam_plan_destroy(void* plan) {
+    if (!plan) return LG_OK;
+    for (const ArmedPlan& a : epi().armed)
+        LG_ARG(a.plan_dev != plan, "lg_adam_plan_destroy: the plan is armed (lg_adam_epilogue_finish first)");
+    return lg_free(plan);
+}
+
+extern "C" int lg_adam_epilogue_arm(const float* grad, int64_t n, const void* plan) {
+    LG_REQUIRE_INIT();
+    LG_ARG(grad && plan && n >= 1, "lg_adam_epilogue_arm: NULL pointer or empty gradient");
+    EpilogueState& E = epi();
+    for (const ArmedPlan& a : E.armed) LG_ARG(a.grad != grad, "lg_adam_epilogue_arm: a plan is already armed for this gradient (lg_adam_epilogue_finish ends a step)");
+    E.armed.push_back(ArmedPlan{grad, static_cast<const AdamPlan*>(plan), n, false});
+    return LG_OK;
+}
+
+extern "C" int lg_adam_epilogue_finish(int* applied_by_kernels, int* applied_here) {
+    LG_REQUIRE_INIT();
+    EpilogueState& E = epi();
+    { const int rc = gemm_group_flush_pending(); if (rc != LG_OK) return rc; }      // queued products write gradients too
+    int taken = 0, left = 0;
+    PlanBatch pb;
+    pb.count = 0;
+    auto flush = [&]() {
+        if (pb.count == 0) return;
+        // (the plans' extents live on the device; the grid is sized for the longest the host knows of)
+        int64_t longest = 0;
+        for (const ArmedPlan& a : E.armed) if (!a.applied && a.n > longest) longest = a.n;
+        hipLaunchKernelGGL(adam_plan_apply, dim3(stream_grid(longest), pb.count), dim3(256), 0, rt().stream, pb);
+        pb.count = 0;
+    };
+    for (const ArmedPlan& a : E.armed) {
+        if (a.applied) { ++taken; continue; }
+        ++left;
+        pb.plan[pb.count] = a.plan_dev;
+        pb.grad[pb.count] = static_cast<const float*>(a.grad);
+        if (++pb.count == kPlanBatch) flush();
+    }
+    flush();
+    E.armed.clear();
+    if (applied_by_kernels) *applied_by_kernels = taken;
+    if (applied_here) *applied_here = left;
+    LG_CHECK_LAUNCH();
     return LG_OK;
 }

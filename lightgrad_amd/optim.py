@@ -82,6 +82,8 @@ class Adam(Optimizer):
         self._step_counter = None
         self._flat = None               # (flat_params, flat_m, flat_v, offsets) once use_flat_buckets() was called
         self._peer_exchange = None
+        self._backward_update = None    # fuse_update_into_backward(): the backend object that arms / finishes every step
+        self.last_step_launched_update = None
 
     def second_moment_input(self, grad, m):
         return grad
@@ -117,9 +119,36 @@ class Adam(Optimizer):
         chunks = sum(-(-(b - a) // 1024) for a, b in zip(offsets[:-1], offsets[1:]))
         self._step_counter = self._flat[0]._new_step_counter(0, slots=chunks)     # one private copy of the step per exchange workgroup
 
+    def fuse_update_into_backward(self) -> None:
+        """let the kernels that PRODUCE the parameter gradients apply this optimizer's update to them (HipTensor: the weight
+        gradient GEMM's epilogue, its bias row sums, the skinny-head backward) - `step()` then launches nothing when every
+        gradient was produced that way, and one kernel for the rest otherwise.  Same values as the update launch, bit for bit.
+        Needs flat buckets; not with a data-parallel exchange (the update needs the SUMMED gradient); every parameter's
+        gradient must be written by one kernel per step (no weight shared between layers: a second writer raises).  The
+        parameters alternate between two buckets: `zero_grad(); backward(); step()` in that order, one backward per step, and
+        an even number of steps inside a captured hipGraph (lightgrad_amd/autograd/hip/tensor.py: BackwardUpdate)."""
+        assert self._flat is not None and hasattr(self._flat[0], "_new_backward_update"), "use_flat_buckets() first (dist.DataParallel(flatten=True).attach)"
+        assert self._peer_exchange is None, "the update cannot ride in the backward kernels when the gradients are exchanged first"
+        assert self.t % max(1, len(self.parameters)) == 0
+        flat_p, flat_m, flat_v, offsets = self._flat
+        self._backward_update = flat_p._new_backward_update(self.parameters, self._flat_grad, flat_m, flat_v, offsets, self.lr, self.b1, self.b2,
+                                                            self.eps, self.grad_scale, self.belief, steps_done=self.t // max(1, len(self.parameters)))
+
+    def zero_grad(self) -> None:
+        Optimizer.zero_grad(self)
+        if self._backward_update is not None:
+            self._backward_update.arm()
+
     @Gradients.no_grad()
     def step(self) -> None:
         n_params = len(self.parameters)
+        if self._backward_update is not None:
+            for p in self.parameters:
+                p._materialize_zero_grad()        # parameters no gradient reached since zero_grad
+            _, here = self._backward_update.finish()
+            self.last_step_launched_update = here > 0
+            self.t += n_params
+            return
         if self._flat is not None:
             for p in self.parameters:
                 p._materialize_zero_grad()        # parameters no gradient reached since zero_grad

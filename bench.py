@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-bert", action="store_true", help="skip the tiny-BERT forward+backward timing")
     ap.add_argument("--no-extras", action="store_true", help="MLP step only: skip matmul / roofline / HBM / BERT / CPU legs")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
+    ap.add_argument("--optimizer-launch", action="store_true",
+                    help="N = 1: keep the optimizer's update as a launch of its own (5 launches per step) instead of letting the backward "
+                         "kernels apply it (optim.Adam.fuse_update_into_backward: 4 launches; same bits)")
     ap.add_argument("--force-comm", action="store_true",
                     help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
@@ -343,6 +346,13 @@ def gpu_rank(args, rank, world):
                                     device_step=use_graph)
         if use_graph:
             dp.attach(opt, exchange_in_optimizer=in_optimizer)        # flat buckets: zero_grad = one flag, update = one launch
+        # one GPU (or a rank training alone): the kernels that make the gradients apply the update themselves - no optimizer launch.
+        # The parameters then alternate between two buckets, so every recorded graph holds an even number of steps.
+        in_backward = (use_graph and (not multi or no_exchange) and not args.optimizer_launch and not args.force_comm
+                       and n_steps % 2 == 0 and min(args.graph_steps, n_steps) >= 2)
+        if in_backward:
+            opt.fuse_update_into_backward()
+        per_graph = 2 if in_backward else 1                     # steps in the "one step" graph
         rng = np.random.RandomState(1000 + rank)         # every rank draws its own batch
         x_np = rng.uniform(0, 1, (1024, 784)).astype(np.float32)
         x = HipTensor.from_numpy(x_np)                   # requires_grad=True like the reference's loop (mnist.py:52-56): dx is computed
@@ -379,21 +389,22 @@ def gpu_rank(args, rank, world):
                 try:
                     g_all = HipGraph()
                     with g_all.capture():
-                        graph_loss = eager_step()
+                        for _ in range(per_graph):
+                            graph_loss = eager_step()
                     comm_in_graph = multi and not no_exchange
                 except L.HipError:
                     raise                        # multi: gpu_rank repeats the leg with host-launched collectives
-                opt.t -= n_params                    # the capture pass ran the python bookkeeping, not the kernels
+                opt.t -= per_graph * n_params        # the capture pass ran the python bookkeeping, not the kernels
             if g_all is not None:
                 def step():
                     g_all.replay()
-                    opt.on_graph_replay()
+                    opt.on_graph_replay(per_graph)
                     return graph_loss
                 # several consecutive steps in ONE graph: the ~8 us the GPU idles between two graph launches (rocprofv3 trace,
                 # tools/step_gap.py) is then paid once per `unroll` steps.  Every recorded step is a complete training step
                 # on the resident batch; the timed loop below still performs exactly --steps of them.
                 unroll = max(1, min(args.graph_steps if not under_profiler else min(args.graph_steps, 8), n_steps))
-                while n_steps % unroll:
+                while n_steps % unroll or unroll % per_graph:
                     unroll -= 1
                 if unroll > 1:
                     g_multi = HipGraph()
@@ -414,7 +425,7 @@ def gpu_rank(args, rank, world):
                     opt.step()
                     return graph_loss
 
-        for _ in range(n_warmup):
+        for _ in range(-(-n_warmup // per_graph) if (use_graph and g_all is not None) else n_warmup):
             loss = step()
         if unroll > 1:
             g_multi.replay()                             # untimed: first launch of the multi-step graph
@@ -427,7 +438,7 @@ def gpu_rank(args, rank, world):
                 opt.on_graph_replay(unroll)
             loss = multi_loss
         else:
-            for _ in range(n_steps):
+            for _ in range(n_steps // (per_graph if (use_graph and g_all is not None) else 1)):
                 loss = step()
         fence()
         mine = time.perf_counter() - t0
@@ -458,7 +469,8 @@ def gpu_rank(args, rank, world):
                 else:
                     step()                          # one replayed step (+ the host-launched exchange and update of the "eager" form)
             fence()
-            long_window = {"steps": reps * unroll, "steps_per_sec": round(world * reps * unroll / wall_max(time.perf_counter() - t0), 2)}
+            per_rep = unroll if unroll > 1 else (per_graph if g_all is not None else 1)
+            long_window = {"steps": reps * per_rep, "steps_per_sec": round(world * reps * per_rep / wall_max(time.perf_counter() - t0), 2)}
 
         # the python tape every step (no graph): what "drop-in behind the autograd surface" costs without capture
         eager_steps = max(10, min(args.steps, 100))
@@ -477,7 +489,7 @@ def gpu_rank(args, rank, world):
             eager_step()
         launches_per_step = None
         if use_graph:
-            launches_per_step = g_all.kernel_count() if g_all is not None else g_fb.kernel_count() + 2      # + host-launched all-reduce and optimizer
+            launches_per_step = g_all.kernel_count() // per_graph if g_all is not None else g_fb.kernel_count() + 2      # + host-launched all-reduce and optimizer
         dispatched_ops = int(sum(fc + bc for _, fc, _, bc in prof.table().values()))      # outermost Function calls, forward + backward
 
         # the same step with the batch marked as data (requires_grad=False): the input gradient, which the reference
@@ -496,18 +508,19 @@ def gpu_rank(args, rank, world):
                 data_step()
             g_data = HipGraph()
             with g_data.capture():
-                data_step()
-            opt.t -= n_params
-            for _ in range(args.warmup):
+                for _ in range(per_graph):
+                    data_step()
+            opt.t -= per_graph * n_params
+            for _ in range(-(-args.warmup // per_graph)):
                 g_data.replay()
             fence()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(max(1, args.steps // per_graph)):
                 g_data.replay()
             fence()
-            data_input_steps_per_s = args.steps / (time.perf_counter() - t0)
-            opt.on_graph_replay(args.warmup + args.steps)
-        return dict(steps_per_s=steps_per_s, elapsed=elapsed, per_rank=per_rank, final_loss=final_loss, first_losses=first_losses,
+            data_input_steps_per_s = max(1, args.steps // per_graph) * per_graph / (time.perf_counter() - t0)
+            opt.on_graph_replay((-(-args.warmup // per_graph) + max(1, args.steps // per_graph)) * per_graph)
+        return dict(steps_per_s=steps_per_s, elapsed=elapsed, per_rank=per_rank, final_loss=final_loss, first_losses=first_losses, in_backward=in_backward,
                     eager_steps_per_s=eager_steps_per_s, dispatched_ops=dispatched_ops, launches_per_step=launches_per_step, long_window=long_window, data_input_steps_per_s=data_input_steps_per_s, comm_in_graph=comm_in_graph,
                     unroll=unroll, use_graph=use_graph, overlap=dp.overlap, w0=w0, x_np=x_np, onehot_np=onehot_np)
 
@@ -550,7 +563,7 @@ def gpu_rank(args, rank, world):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "mnist_mlp_784x512x10_bias_batch1024_mse_adabelief_lr1e-3 (fwd+bwd+allreduce+optimizer)",
                        "batch_per_gpu": 1024, "global_batch": 1024 * world, "parallelism": "dp%d" % world,
-                       "optimizer_kernel": "tape" if args.no_fused_optimizer else "fused",
+                       "optimizer_kernel": "tape" if args.no_fused_optimizer else ("applied by the backward kernels (no launch of its own)" if R["in_backward"] else "fused"),
                        "input_requires_grad": True,
                        "dispatch": ("hipGraph replay (python tape captured once; %d consecutive steps per graph)" % R["unroll"]) if R["use_graph"] else "eager python tape",
                        "steps_per_graph": R["unroll"],
@@ -783,6 +796,38 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
                 "frac": round(gemm_tf["NN"] / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(gemm_ms["NN"], 4), "algorithmic_flop_per_launch": 2 * n ** 3}
     del c
+    # ---- the roofline of the HEADLINE step's own kernels: the two MFMA launches of the MLP step, timed the same
+    # way through the C ABI on operands of the step's shapes - the forward product of the first layer (bias epilogue) and the
+    # launch that makes dW1 (+ db1 as row sums) and dx together (lg_gemm_pair_*); the other two launches of the step (the
+    # N = 10 head, forward and backward) move 2 MB and do 10 MFLOP each: launch latency, no roofline to speak of
+    rs = np.random.RandomState(5 + rank)
+    B_, I_, H_ = 1024, 784, 512
+    sx = HipTensor.from_numpy(rs.uniform(0, 1, (B_, I_)).astype(np.float32), requires_grad=False)
+    sw = HipTensor.from_numpy((rs.uniform(-1, 1, (H_, I_)) / np.sqrt(H_ * I_)).astype(np.float32), requires_grad=False)
+    sb = HipTensor.from_numpy(rs.uniform(-1, 1, (H_,)).astype(np.float32), requires_grad=False)
+    sg = HipTensor.from_numpy(rs.uniform(-1, 1, (B_, H_)).astype(np.float32), requires_grad=False)
+    sy, sdw, sdb, sdx = (HipTensor.empty(shape, requires_grad=False) for shape in ((B_, H_), (H_, I_), (H_,), (B_, I_)))
+
+    def step_forward():        # pre = x @ W1^T + b1
+        L.check(lib.lg_gemm_bias_f32(0, 1, B_, H_, I_, sx.ptr, I_, 0, sw.ptr, I_, 0, sy.ptr, H_, 0, 1, sb.ptr))
+
+    def step_backward():       # dW1 (+ db1) = g^T @ x and dx = g @ W1 in one launch
+        L.check(lib.lg_gemm_pair_begin())
+        L.check(lib.lg_gemm_rowsum_f32(1, 0, H_, I_, B_, sg.ptr, H_, sx.ptr, I_, sdw.ptr, I_, 0, sdb.ptr, 0))
+        L.check(lib.lg_gemm_f32(0, 0, B_, I_, H_, sg.ptr, H_, 0, sw.ptr, I_, 0, sdx.ptr, I_, 0, 1, 0))
+        L.check(lib.lg_gemm_pair_end())
+    fwd_us = 1e3 * time_launches(step_forward, 20)
+    bwd_us = 1e3 * time_launches(step_backward, 20)
+    fwd_flop, bwd_flop = 2 * B_ * H_ * I_, 2 * 2 * B_ * H_ * I_
+    roofline_step = {
+        "kernel": "sgemm_pair_wgrad_xgrad (dW1 + db1 = g^T @ x and dx = g @ W1 in one launch): the dominant kernel of the MLP step",
+        "bound": "mfma", "algorithmic_flop_per_launch": bwd_flop, "avg_launch_us": round(bwd_us, 2),
+        "achieved": round(bwd_flop / bwd_us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(bwd_flop / bwd_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+        "forward_product": {"kernel": "sgemm_mfma 1024x512x784 NT + bias", "algorithmic_flop_per_launch": fwd_flop, "avg_launch_us": round(fwd_us, 2),
+                            "achieved": round(fwd_flop / fwd_us / 1e6, 2), "frac": round(fwd_flop / fwd_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
+        "how": "HIP events on the library stream around 20 back-to-back launches through the C ABI (launch boundaries included), median of 3"}
+    del sx, sw, sb, sg, sy, sdw, sdb, sdx
     # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache).  The
     # operands hold RANDOM data (a 16 MiB random block repeated; constants switch fewer wires and read high)
     big = (16384, 8192)
@@ -914,6 +959,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
                               "launches_per_iter": bert_launches,
                               "hipgraph_replays_timed": bert_replays, "profiler_attached": under_profiler},
         "roofline": roofline,
+        "roofline_step": roofline_step,
         "roofline_hbm": hbm,
         "cpu_baseline": cpu_baseline,
     }

@@ -330,6 +330,7 @@ int lg_adam_plan_create(void** plan, const float* p_in, float* p_out, float* m, 
 int lg_adam_plan_destroy(void* plan);
 int lg_adam_epilogue_arm(const float* grad, int64_t n, const void* plan);
 int lg_adam_epilogue_finish(int* applied_by_kernels, int* applied_here);
+int lg_adam_epilogue_disarm(void);       /* forget everything armed without applying it (after a failed backward pass) */
 
 /* ---- fused loss ----------------------------------------
  * loss.mse forward (loss.py:4-10) for dense fp32 tensors of n elements:

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "lg_adam_plan_destroy": (c_int, [c_void_p]),
     "lg_adam_epilogue_arm": (c_int, [c_void_p, c_int64, c_void_p]),
     "lg_adam_epilogue_finish": (c_int, [POINTER(c_int), POINTER(c_int)]),
+    "lg_adam_epilogue_disarm": (c_int, []),
     "lg_gemm_bias_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "lg_gemm_addend_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

@@ -241,9 +241,18 @@ class BackwardUpdate(object):
     def current_bucket(self):
         return self.buckets[self.parity]
 
+    def disarm(self) -> None:
+        """after a backward pass that failed: forget the armed updates (some may have been applied: the parameters are then
+        not to be trusted - this only makes the library usable again)"""
+        if self.armed:
+            _l.check(_l.lib().lg_adam_epilogue_disarm())
+            self.armed = False
+
     def __del__(self):
         if _l._lib is None:
             return
+        if self.armed:
+            _l._lib.lg_adam_epilogue_disarm()
         for direction in (0, 1):
             for plan in self.plans[direction]:
                 if plan is not None:

@@ -365,6 +365,11 @@ extern "C" int lg_adam_epilogue_arm(const float* grad, int64_t n, const void* pl
     return LG_OK;
 }
 
+extern "C" int lg_adam_epilogue_disarm(void) {
+    epi().armed.clear();
+    return LG_OK;
+}
+
 extern "C" int lg_adam_epilogue_finish(int* applied_by_kernels, int* applied_here) {
     LG_REQUIRE_INIT();
     EpilogueState& E = epi();

@@ -159,3 +159,4 @@ def test_a_weight_shared_by_two_layers_is_refused(hip):
     opt.zero_grad()
     with pytest.raises(HipError, match="again after its optimizer update was applied"):
         loss.backward()
+    opt._backward_update.disarm()

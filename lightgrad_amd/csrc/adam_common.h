@@ -47,6 +47,14 @@ struct AdamPlan {
     int64_t        t_mul, t_add;   // t = steps_done * t_mul + t_add (the reference advances t once per PARAMETER, optim.py:36/:48)
     double         b1, b2;
     AdamScalars    c;           // inv_bias1 / inv_bias2 are filled in on the device
+    // The bias corrections 1/(1 - b^t) of every step this plan will ever see, made on the HOST when the plan is created
+    // (libm pow in double, rounded once to fp32: the python expression `(1 - self.b1**self.t)` to the letter): entry s holds the
+    // pair for steps_done == s; from entry table_steps - 1 on both are exactly 1.0f (b^t < 2^-25).  Two double-precision pow()
+    // by one lane cost a wavefront ~2 us - in an epilogue that sits on the critical path of its launch they cost more than the
+    // optimizer launch they replace (measured: the MLP step 59.7 -> 64.7 us with them, bench_v1 of round 4).  NULL: too many
+    // steps to tabulate (b2 very close to 1): the powers are formed on the device as before.
+    const float*   table;
+    int64_t        table_steps;
 };
 
 // the scalars of this step for one wavefront: lane 0 reads the step number and forms the two double-precision powers
@@ -54,6 +62,13 @@ struct AdamPlan {
 // of a workgroup are still alive
 __device__ __forceinline__ AdamScalars adam_plan_scalars(const AdamPlan* pl, int64_t& steps_done) {
     AdamScalars c = pl->c;
+    if (pl->table) {                          // uniform: kernel-argument pointer, scalar loads
+        steps_done = pl->step_in[0];
+        const int64_t s = steps_done < pl->table_steps ? steps_done : pl->table_steps - 1;
+        c.inv_bias1 = pl->table[2 * s];
+        c.inv_bias2 = pl->table[2 * s + 1];
+        return c;
+    }
     float i1 = 0.f, i2 = 0.f;
     long long done = 0;
     if ((threadIdx.x & 63) == 0) {

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "adam_common.h"
 #include <vector>
+#include <cmath>
 
 namespace lg {
 
@@ -340,11 +341,29 @@ extern "C" int lg_adam_plan_create(void** plan, const float* p_in, float* p_out,
     h.p_in = p_in; h.p_out = p_out; h.m = m; h.v = v; h.step_in = step_in; h.step_out = step_out; h.n = n;
     h.t_mul = t_mul; h.t_add = t_add; h.b1 = b1; h.b2 = b2;
     h.c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
+    // the bias corrections of every step, tabulated until both have become exactly 1.0f (header: AdamPlan::table)
+    std::vector<float> table;
+    constexpr int64_t kMaxTableSteps = int64_t(1) << 21;
+    if (b1 >= 0.0 && b1 < 1.0 && b2 >= 0.0 && b2 < 1.0 && t_mul >= 1 && t_add >= 1) {
+        for (int64_t s = 0; s < kMaxTableSteps; ++s) {
+            const double t = double(s * t_mul + t_add);
+            const float i1 = float(1.0 / (1.0 - pow(b1, t))), i2 = float(1.0 / (1.0 - pow(b2, t)));
+            table.push_back(i1);
+            table.push_back(i2);
+            if (i1 == 1.0f && i2 == 1.0f) break;
+        }
+        if (table[table.size() - 2] != 1.0f || table.back() != 1.0f) table.clear();       // did not converge within the cap
+    }
     void* d = nullptr;
-    int rc = lg_malloc(&d, sizeof(AdamPlan));
+    int rc = lg_malloc(&d, sizeof(AdamPlan) + table.size() * sizeof(float));
     if (rc != LG_OK) return rc;
+    if (!table.empty()) {
+        h.table = reinterpret_cast<const float*>(static_cast<char*>(d) + sizeof(AdamPlan));
+        h.table_steps = int64_t(table.size() / 2);
+        LG_HIP(hipMemcpyAsync(static_cast<char*>(d) + sizeof(AdamPlan), table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice, rt().stream));
+    }
     LG_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, rt().stream));
-    LG_HIP(hipStreamSynchronize(rt().stream));          // `h` lives on this stack frame
+    LG_HIP(hipStreamSynchronize(rt().stream));          // `h` and `table` live on this stack frame
     *plan = d;
     return LG_OK;
 }

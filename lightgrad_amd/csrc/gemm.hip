@@ -134,8 +134,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + pos;
 }
 
-// the 256x256 tile never splits K (its launches have >= 256 tiles or lose to smaller tiles in the cost model); leaving
-// the fold out of that instantiation keeps its main loop free of spills
+// the 256x256 tile never splits K (its launches have >= 256 tiles or lose to smaller tiles in the cost model); it also leaves
+// out everything else optional - with 64 of its 128 registers per lane holding accumulators it has none to spare (its four
+// shipped instantiations use exactly 128 and no scratch: tests/test_gemm_registers.py compiles them and checks)
 template <int BM, int BN> constexpr bool kHasExtras = BM * BN < 256 * 256;      // relu operands, row sums: small tiles only
 template <int BM, int BN, int KG = 1> constexpr bool kCanSplitK = kHasExtras<BM, BN> && KG == 1;
 // the optimizer's update in the epilogue (lg_adam_epilogue_arm): tiles up to 128x128 with one K-group
@@ -146,10 +147,22 @@ template <int BM, int BN, int KG = 1> constexpr bool kCanAdam = BM * BN <= 128 *
 // group 0 through LDS.  For outputs with too few 64x64 tiles to fill the chip this replaces the cross-workgroup split-K (slab
 // write + drain + ticket + fold = 2.6 us of a 14.6 us launch, profiles/r2/gemm_timeline_v1.txt) by one LDS exchange: a 64x32
 // tile with 2 x 2 waves does per wave exactly the MFMA work of a 64x64 tile with 2 K-slices, one workgroup per CU.
+// gather staging (gemm_tile_body.inc): an M- / N-contiguous operand of the 256x256 tile is transposed on its way to LDS.
+// EXPERIMENT, off in the shipped library (-DLG_GEMM_GATHER_STAGING builds it): the four dwords of a chunk land in four
+// separately allocated registers (an inline-asm load cannot target an element of a register tuple) and packing them for the
+// 16-byte LDS store costs the 128-register tile 9-20 spilled registers inside its K loop (round 4, tools: /tmp build of the
+// 256x256 instantiations only; profiles/r4/README.md).  The lead that remains: loads the compiler can see (no inline asm), at
+// the price of its conservative vmcnt waits, or fragments read as ds_read_b64 along m / n with the accumulator rows permuted.
+#ifdef LG_GEMM_GATHER_STAGING
+template <int BM, int BN, bool XKC> constexpr bool kGatherStaging = !XKC && BM * BN == 256 * 256;
+#else
+template <int BM, int BN, bool XKC> constexpr bool kGatherStaging = false;
+#endif
 template <int BM, int BN, int BK, bool AKC, bool BKC, int KG>
 constexpr int gemm_lds_floats() {
     constexpr int BKS = BK * KG;
-    return 2 * ((AKC ? BM * (BKS + 4) : BKS * BM) + (BKC ? BN * (BKS + 4) : BKS * BN));
+    constexpr bool ALK = AKC || kGatherStaging<BM, BN, AKC>, BLK = BKC || kGatherStaging<BM, BN, BKC>;
+    return 2 * ((ALK ? BM * (BKS + 4) : BKS * BM) + (BLK ? BN * (BKS + 4) : BKS * BN));
 }
 
 // The kernel body lives in gemm_tile_body.inc and is included textually: here as the whole kernel, and twice - once per
@@ -300,12 +313,30 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
     hipStream_t s = rt().stream;
     // K-tiles in flight between global memory and LDS.  The large tiles ran with ONE until the end of round 3 ("enough MFMAs per
     // K-tile to cover the latency"): with two, 4096^3 NN 140.9 -> 143.3, NT 143.0 -> 146.6 TFLOP/s on the 256 x 256 tile (TN 138,
-    // unchanged: both its operands come out of LDS as single floats), 132 -> 136-137 on the 128 x 128 tile; three spills.
+    // unchanged: both its operands come out of LDS as single floats), 132 -> 136-137 on the 128 x 128 tile.
+    //
+    // NOT three on the 256 x 256 tile, and why (the "memory access fault" of round 3's experiment): the ring
+    // registers are written by inline-asm buffer loads that the compiler believes complete at once.  A third slot makes the
+    // ring 48 registers next to 64 accumulators - more than the 128 a lane of a 1024-thread workgroup has - so the allocator
+    // SPILLS ring registers (the experiment's 112-192 bytes of scratch): it stores such a register right behind the asm
+    // statement, i.e. BEFORE the load has landed, hands the physical register to another value - an LDS or global address, a
+    // loop bound - and the load then lands on top of that value.  A wild address is the fault; the reloaded "tile" is garbage
+    // even when nothing faults.  The ring's slot arithmetic and vmcnt counts are sound for any PD (the wait in front of
+    // tile kt+1 always leaves at most PD-2 younger tiles = (PD-2)*NL loads outstanding; gemm_tile_body.inc).  So the rule is:
+    // a kernel whose ring is in flight across compiler-scheduled code must not spill - the shipped 256 x 256 instantiations
+    // are checked for zero scratch (tests/test_gemm_registers.py), and deeper rings on this tile do not build:
     constexpr int PD = (BM * BN <= 64 * 64) ? kSmallTilePrefetch : 2;
+    static_assert(BM * BN < 256 * 256 || PD <= 2, "a third K-tile in flight does not fit the 256x256 tile's 128 registers: ring registers would spill while their loads are in flight");
     if constexpr (kHasExtras<BM, BN>) {
         // (the entry points have checked: multi comes K-contiguous on both sides, seg_k with an N-contiguous B, float4 staging)
         if constexpr (AKC && BKC)  { if (g.multi) { hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG, 1>), grid, block, 0, s, g); return; } }
         if constexpr (AKC && !BKC) { if (g.seg_k) { hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG, 2>), grid, block, 0, s, g); return; } }
+    }
+    if constexpr (!kHasExtras<BM, BN>) {
+        // the 256x256 tile exists in its float4 / gather form only (gemm_impl: va is always set, vb unless row sums ride along -
+        // and those never take this tile)
+        hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG>), grid, block, 0, s, g);
+        return;
     }
     if (va && vb)  hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, true, PD, KG>), grid, block, 0, s, g);
     else if (va)   hipLaunchKernelGGL((sgemm_mfma<BM, BN, BK, WM, WN, AKC, BKC, true, false, 1, KG>), grid, block, 0, s, g);

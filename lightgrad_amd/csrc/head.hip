@@ -168,6 +168,12 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
         // the optimizer's update of the values the writer threads store at the end (lg_adam_epilogue_arm): parameter and
         // moments are requested now, their round trip runs under the reduction (in the final section it cost 1.7 us)
         float adam_P = 0.f, adam_M = 0.f, adam_V = 0.f;
+        AdamScalars cw, cb;
+        int64_t done_w = 0, done_b = 0;
+        if (tid < 192) {                               // (whole wavefronts: lane 0 may have to form the scalars for the others)
+            if (a.adam_w) cw = adam_plan_scalars(a.adam_w, done_w);
+            if (a.adam_b && slab == 0) cb = adam_plan_scalars(a.adam_b, done_b);
+        }
         if ((a.adam_w || a.adam_b) && tid < OMAX * (kSlabCols + 1)) {
             const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
             const int kk = slab * kSlabCols + c;
@@ -235,11 +241,7 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
         __syncthreads();
         static_assert(OMAX * (kSlabCols + 1) <= 192, "the writers below are the first three wavefronts");
         if (tid < 192) {
-            // (whole wavefronts enter: the step's scalars are formed by lane 0 and handed to the others)
-            AdamScalars cw, cb;
-            int64_t done_w = 0, done_b = 0;
-            if (a.adam_w) cw = adam_plan_scalars(a.adam_w, done_w);
-            if (a.adam_b && slab == 0) cb = adam_plan_scalars(a.adam_b, done_b);
+            // (the step's scalars were requested at the top of the workgroup)
             if (tid < OMAX * (kSlabCols + 1)) {
                 const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
                 if (j < a.outs && (c < kSlabCols || slab == 0)) {

@@ -783,7 +783,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
     # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (profiles/rN/pmc_traffic.json; separate runs,
     # corrected as MI355X_MICROARCH.md prescribes) - cannot be collected from inside this process
     traffic = None
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                 traffic = json.load(f).get("sgemm_mfma_256x256_NN_4096", {}).get("hbm_bytes_per_launch")

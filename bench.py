@@ -48,9 +48,10 @@ def parse():
     ap.add_argument("--no-bert", action="store_true", help="skip the tiny-BERT forward+backward timing")
     ap.add_argument("--no-extras", action="store_true", help="MLP step only: skip matmul / roofline / HBM / BERT / CPU legs")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
-    ap.add_argument("--optimizer-launch", action="store_true",
-                    help="N = 1: keep the optimizer's update as a launch of its own (5 launches per step) instead of letting the backward "
-                         "kernels apply it (optim.Adam.fuse_update_into_backward: 4 launches; same bits)")
+    ap.add_argument("--update-in-backward", action="store_true",
+                    help="N = 1: let the backward kernels apply the optimizer's update (optim.Adam.fuse_update_into_backward: 4 launches per "
+                         "step instead of 5, same bits).  Not the default: measured on MI355X it moves the 6 us of the update launch into the "
+                         "tails of the two launches that make the gradients and the step stays where it was (profiles/r4/README.md)")
     ap.add_argument("--force-comm", action="store_true",
                     help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
@@ -346,9 +347,9 @@ def gpu_rank(args, rank, world):
                                     device_step=use_graph)
         if use_graph:
             dp.attach(opt, exchange_in_optimizer=in_optimizer)        # flat buckets: zero_grad = one flag, update = one launch
-        # one GPU (or a rank training alone): the kernels that make the gradients apply the update themselves - no optimizer launch.
-        # The parameters then alternate between two buckets, so every recorded graph holds an even number of steps.
-        in_backward = (use_graph and (not multi or no_exchange) and not args.optimizer_launch and not args.force_comm
+        # --update-in-backward, one GPU (or a rank training alone): the kernels that make the gradients apply the update themselves -
+        # no optimizer launch.  The parameters then alternate between two buckets, so every recorded graph holds an even number of steps.
+        in_backward = (use_graph and (not multi or no_exchange) and args.update_in_backward and not args.force_comm
                        and n_steps % 2 == 0 and min(args.graph_steps, n_steps) >= 2)
         if in_backward:
             opt.fuse_update_into_backward()

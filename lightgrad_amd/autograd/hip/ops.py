@@ -1023,22 +1023,30 @@ def _table_rows_grad(table, shape, idx, out_grad):
     return _scatter_add_rows(shape, idx, out_grad)
 
 
-_TILED_IDS = {}
-
-
 def _tiled_ids(ids, shape):
-    """the id tensor `ids` repeated along leading axes up to `shape`, as a dense tensor of its own (made once per id tensor and
-    shape: position ids are constants of a model)"""
-    key = (id(ids.data), ids._offset, ids._shape, tuple(shape))
-    hit = _TILED_IDS.get(key)
-    if hit is not None and hit[0]() is ids.data:
-        return hit[1]
+    """the id tensor `ids` repeated along leading axes up to `shape`, as a dense tensor of its own.  Position ids are constants
+    of a model, so the copy is kept with the id tensor's STORAGE (HipBuffer.derived) - every in-place writer into that storage
+    (upload_, setitem, fill: tensor.flush_lazy_readers) drops it, and inside a hipGraph capture it is made anew each time, so
+    that a replay tiles whatever the id buffer holds then."""
+    from .graph import HipGraph
+    buf = ids.data
+    key = (ids._offset, ids._shape, ids._strides, tuple(shape))
+    if not HipGraph.capturing and buf.derived is not None:
+        hit = buf.derived.get(key)
+        if hit is not None:
+            return hit
     lead = len(shape) - len(ids._shape)
-    tiled = HipTensor(ids.data, tuple(shape), (0,) * lead + tuple(ids._strides), ids._offset, ids._dtype, requires_grad=False).contiguous()
-    if len(_TILED_IDS) > 64:
-        _TILED_IDS.clear()
-    _TILED_IDS[key] = (weakref.ref(ids.data), tiled)
+    tiled = HipTensor(buf, tuple(shape), (0,) * lead + tuple(ids._strides), ids._offset, ids._dtype, requires_grad=False).contiguous()
+    if not HipGraph.capturing:
+        if buf.derived is None:
+            buf.derived = {}
+        buf.derived[key] = tiled
     return tiled
+
+
+# repeats of a shared id (position ids over a batch) up to which the scatter-add of the tiled ids stays in position order
+# without atomics: csrc/tail_jobs.h kChunk
+_SCATTER_ORDERED_REPEATS = 32
 
 
 @HipTensor.register_op()
@@ -1075,9 +1083,19 @@ class embedding_sum(Function):
                 continue
             g = out_grad
             if i._shape != ids[0]._shape:
-                # ids shared by leading axes (position ids of a batch): every output row is scattered with its own copy of the id -
-                # the scatter-add sums the repeats in position order, no separate sum over the batch in front of it
-                i = _tiled_ids(i, ids[0]._shape)
+                lead = len(ids[0]._shape) - len(i._shape)
+                repeats = 1
+                for n in ids[0]._shape[:lead]:
+                    repeats *= n
+                if repeats <= _SCATTER_ORDERED_REPEATS:
+                    # ids shared by leading axes (position ids of a batch): every output row is scattered with its own copy of
+                    # the id - the scatter-add sums the repeats in position order, no separate sum over the batch in front of it
+                    i = _tiled_ids(i, ids[0]._shape)
+                else:
+                    # more repeats than one ordered chunk of the scatter kernel holds: every shared id would be a "hot" row summed
+                    # with float atomics (not reproducible, not the reference's order).  The tape's own form instead: the sum over
+                    # the leading axes first (func.py:50-56's un-broadcast), then one ordered scatter
+                    g = _reduce(_l.RED_SUM, out_grad.contiguous(), tuple(range(lead)), False)
             grads.append(_table_rows_grad(table, shape, i, g))
         return tuple(grads)
 

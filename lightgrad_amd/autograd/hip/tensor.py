@@ -38,11 +38,12 @@ def contiguous_strides(shape):
 
 class HipBuffer(object):
     """Owner of one pool allocation; returned to the pool when the last tensor viewing it dies."""
-    __slots__ = ("ptr", "nbytes", "lazy_readers", "__weakref__")
+    __slots__ = ("ptr", "nbytes", "lazy_readers", "derived", "__weakref__")
 
     def __init__(self, nbytes):
         self.ptr = None
         self.lazy_readers = None      # weak references to lazy tensors that will still READ this block (see flush_lazy_readers)
+        self.derived = None           # tensors computed from this block's CONTENTS and kept for reuse (ops._tiled_ids): dropped by any in-place writer
         p = ctypes.c_void_p()
         _l.check(_l.lib().lg_malloc(ctypes.byref(p), max(int(nbytes), 1)))
         self.ptr = p.value
@@ -142,6 +143,9 @@ def flush_lazy_readers(t) -> None:
     if GradGroup.touched and not GradGroup.issuing and id(t._data) in GradGroup.touched:
         GradGroup.flush()              # storage that a queued launch will read or write
     _make_lazy_readers_real(t)
+    buf = t._data
+    if buf is not None and buf.derived is not None:
+        buf.derived = None             # cached results made from the old contents (ids tiled once, then refreshed in place)
 
 
 def _make_lazy_readers_real(t) -> None:

@@ -165,25 +165,6 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
         float acc[OMAX], dbacc[OMAX];
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) { acc[j] = 0.f; dbacc[j] = 0.f; }
-        // the optimizer's update of the values the writer threads store at the end (lg_adam_epilogue_arm): parameter and
-        // moments are requested now, their round trip runs under the reduction (in the final section it cost 1.7 us)
-        float adam_P = 0.f, adam_M = 0.f, adam_V = 0.f;
-        AdamScalars cw, cb;
-        int64_t done_w = 0, done_b = 0;
-        if (tid < 192) {                               // (whole wavefronts: lane 0 may have to form the scalars for the others)
-            if (a.adam_w) cw = adam_plan_scalars(a.adam_w, done_w);
-            if (a.adam_b && slab == 0) cb = adam_plan_scalars(a.adam_b, done_b);
-        }
-        if ((a.adam_w || a.adam_b) && tid < OMAX * (kSlabCols + 1)) {
-            const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
-            const int kk = slab * kSlabCols + c;
-            if (j < a.outs && c < kSlabCols && kk < a.hidden && a.adam_w && a.dw) {
-                const int64_t idx = int64_t(j) * a.hidden + kk;
-                adam_P = a.adam_w->p_in[idx]; adam_M = a.adam_w->m[idx]; adam_V = a.adam_w->v[idx];
-            } else if (j < a.outs && c == kSlabCols && slab == 0 && a.adam_b && a.db) {
-                adam_P = a.adam_b->p_in[j]; adam_M = a.adam_b->m[j]; adam_V = a.adam_b->v[j];
-            }
-        }
         for (int64_t c0 = 0; c0 < a.rows; c0 += CHUNK) {
             float xv[RPT];
 #pragma unroll
@@ -241,7 +222,11 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
         __syncthreads();
         static_assert(OMAX * (kSlabCols + 1) <= 192, "the writers below are the first three wavefronts");
         if (tid < 192) {
-            // (the step's scalars were requested at the top of the workgroup)
+            // (whole wavefronts enter: the step's scalars are formed by lane 0 and handed to the others)
+            AdamScalars cw, cb;
+            int64_t done_w = 0, done_b = 0;
+            if (a.adam_w) cw = adam_plan_scalars(a.adam_w, done_w);
+            if (a.adam_b && slab == 0) cb = adam_plan_scalars(a.adam_b, done_b);
             if (tid < OMAX * (kSlabCols + 1)) {
                 const int j = tid / (kSlabCols + 1), c = tid % (kSlabCols + 1);
                 if (j < a.outs && (c < kSlabCols || slab == 0)) {
@@ -255,16 +240,18 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
                             const float gv = a.dw_accumulate ? a.dw[idx] + s : s;
                             a.dw[idx] = gv;
                             if (a.adam_w) {
-                                adam_elem(adam_P, gv, adam_M, adam_V, cw);
-                                a.adam_w->p_out[idx] = adam_P; a.adam_w->m[idx] = adam_M; a.adam_w->v[idx] = adam_V;
+                                float P = a.adam_w->p_in[idx], M = a.adam_w->m[idx], V = a.adam_w->v[idx];
+                                adam_elem(P, gv, M, V, cw);
+                                a.adam_w->p_out[idx] = P; a.adam_w->m[idx] = M; a.adam_w->v[idx] = V;
                             }
                         }
                     } else if (a.db) {
                         const float gv = a.db_accumulate ? a.db[j] + s : s;
                         a.db[j] = gv;
                         if (a.adam_b) {
-                            adam_elem(adam_P, gv, adam_M, adam_V, cb);
-                            a.adam_b->p_out[j] = adam_P; a.adam_b->m[j] = adam_M; a.adam_b->v[j] = adam_V;
+                            float P = a.adam_b->p_in[j], M = a.adam_b->m[j], V = a.adam_b->v[j];
+                            adam_elem(P, gv, M, V, cb);
+                            a.adam_b->p_out[j] = P; a.adam_b->m[j] = M; a.adam_b->v[j] = V;
                         }
                     }
                 }

@@ -118,3 +118,43 @@ def rel_frobenius(got, ref):
 # one encoder layer of BERT at sizes the fused attention kernels take (d = 32, 32 positions): tests/dist_rank_worker.py `bert` mode
 DIST_BERT_CFG = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=60,
                      max_position_embeddings=32, type_vocab_size=2)
+
+
+# ---- the float64 yardstick for multi-step results (Weak 1) ------------------------------------------------------
+# A k-step trajectory amplifies float32 rounding noise (AdaBelief divides by the square root of a second moment that starts
+# near zero), so two correct float32 runs end 1e-4 apart and say little about each other.  The SAME tape code run on CpuTensor
+# in float64 is (nearly) exact: a float32 result is judged by its distance to that - it must be within the north star's 1e-5
+# (relative Frobenius) or no further away than twice what the float32 CPU backend itself is.
+def mlp_trajectory_on_cpu(w0, x, onehot, steps, make_optimizer, dtype):
+    """(losses, {name: final weights}) of `steps` training steps of the MLP on CpuTensor in `dtype`; make_optimizer(parameters)"""
+    import lightgrad_amd as light
+    from lightgrad_amd import CpuTensor
+    from test_cpu_backend import MLP
+    d_in, d_hid, d_out = w0["l1.weight"].shape[1], w0["l1.weight"].shape[0], w0["l2.weight"].shape[0]
+
+    def run():
+        model = MLP(d_in, d_hid, d_out)
+        model.load_parameters({n: a.astype(dtype) for n, a in w0.items()})
+        assert all(p.dtype == dtype for p in model.parameters())
+        opt = make_optimizer(model.parameters())
+        tx, tt = CpuTensor.from_numpy(x.astype(dtype)), CpuTensor.from_numpy(onehot.astype(dtype))
+        losses = []
+        for _ in range(steps):
+            l = light.loss.mse(model(tx), tt)
+            opt.zero_grad()
+            l.backward()
+            opt.step()
+            losses.append(l.item())
+        return losses, {n: p.numpy().copy() for n, p in model.named_parameters()}
+    if np.dtype(dtype) == np.float64:
+        with float64_tape():
+            return run()
+    return run()
+
+
+def assert_as_close_to_float64_as_the_cpu_backend(got: dict, cpu32: dict, ref64: dict, floor=1e-5, what=""):
+    """every array of `got` within `floor` (relative Frobenius) of the float64 result, or no further from it than twice the float32
+    CPU backend's own distance"""
+    for n in ref64:
+        e_got, e_cpu = rel_frobenius(got[n], ref64[n]), rel_frobenius(cpu32[n], ref64[n])
+        assert e_got <= max(floor, 2 * e_cpu), "%s %s: %.3g from the float64 run, the float32 CPU backend %.3g" % (what, n, e_got, e_cpu)

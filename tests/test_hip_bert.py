@@ -360,6 +360,75 @@ def test_embedding_sum_is_the_three_lookups_and_two_adds(hip, dtype):
         out.numpy()
 
 
+def _embedding_sum_grads(T, tables, ids, pos, kind, w, fused):
+    ts = [T.from_numpy(t) for t in tables]
+    i0, i1, i2 = (T.from_numpy(x, requires_grad=False) for x in (ids, pos, kind))
+    out = ts[0].embedding_sum(ts[1], ts[2], ids0=i0, ids1=i1, ids2=i2) if fused else (ts[0][i0] + ts[1][i1]) + ts[2][i2]
+    (out * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+    return [t.grad.numpy() for t in ts], (ts, (i0, i1, i2))
+
+
+@pytest.mark.parametrize("batch", [4, 64], ids=["repeats_within_one_ordered_chunk", "batch_64_more_repeats_than_a_chunk"])
+def test_embedding_sum_gradients_of_shared_ids_follow_the_tape_at_any_batch(hip, batch):
+    """position / token-type ids shared by the batch: with more repeats than the scatter kernel sums in order (32) the
+    gradient takes the tape's form - sum over the batch, then one ordered scatter - and stays bit-reproducible; either way it is the
+    numpy CPU backend's gradient of the composite line"""
+    from lightgrad_amd import CpuTensor
+    rng = np.random.RandomState(16)
+    s, width = 12, 8
+    tables = [rng.uniform(-1, 1, (n, width)).astype(np.float32) for n in (30, 12, 2)]
+    ids = rng.randint(0, 30, (batch, s)).astype(np.int32)
+    pos = np.arange(s, dtype=np.int32)
+    kind = (np.arange(s) >= 5).astype(np.int32)                        # token types: shared by the batch too, only two rows
+    w = rng.uniform(-1, 1, (batch, s, width)).astype(np.float32)
+    want, _ = _embedding_sum_grads(CpuTensor, tables, ids, pos, kind, w, fused=False)
+    got, _ = _embedding_sum_grads(hip, tables, ids, pos, kind, w, fused=True)
+    again, _ = _embedding_sum_grads(hip, tables, ids, pos, kind, w, fused=True)
+    for g, a, c, name in zip(got, again, want, ("word", "position", "token type")):
+        np.testing.assert_array_equal(g, a, err_msg=name)                # run to run: the same bits
+        np.testing.assert_allclose(g, c, rtol=1e-5, atol=1e-5 * np.abs(c).max(), err_msg=name)
+    if batch > 32:                                                     # the tape's order exactly: sum over the batch, then np.add.at
+        np.testing.assert_array_equal(got[1], want[1])
+
+
+def test_shared_ids_refreshed_in_place_are_tiled_again(hip):
+    """the tiled copy of a shared id tensor is kept with the tensor's storage - an in-place refresh of the ids (upload_, setitem)
+    between two backward passes must not leave the old copy in use"""
+    rng = np.random.RandomState(17)
+    batch, s, width = 4, 6, 8
+    tables = [rng.uniform(-1, 1, (n, width)).astype(np.float32) for n in (20, 10, 3)]
+    ids = rng.randint(0, 20, (batch, s)).astype(np.int32)
+    w = rng.uniform(-1, 1, (batch, s, width)).astype(np.float32)
+    pos_a, pos_b = np.arange(s, dtype=np.int32), np.arange(s, dtype=np.int32)[::-1].copy() + 3
+    kind = np.zeros(s, np.int32)
+    ts = [hip.from_numpy(t) for t in tables]
+    i0, i1, i2 = (hip.from_numpy(x, requires_grad=False) for x in (ids, pos_a, kind))
+    tw = hip.from_numpy(w, requires_grad=False)
+
+    def position_gradient():
+        for t in ts:
+            t.zero_grad()
+        (ts[0].embedding_sum(ts[1], ts[2], ids0=i0, ids1=i1, ids2=i2) * tw).backward(allow_fill=True)
+        return ts[1].grad.numpy().copy()
+    first = position_gradient()
+    want_a = np.zeros_like(tables[1])
+    np.add.at(want_a, pos_a, w.sum(0))
+    np.testing.assert_allclose(first, want_a, rtol=1e-5, atol=1e-6)
+    for refresh in ("upload", "setitem", "fill"):
+        if refresh == "upload":
+            i1.upload_(pos_b)
+            now = pos_b
+        elif refresh == "setitem":
+            i1[...] = hip.from_numpy(pos_a, requires_grad=False)
+            now = pos_a
+        else:
+            i1.fill(7)
+            now = np.full(s, 7, np.int32)
+        want = np.zeros_like(tables[1])
+        np.add.at(want, now, w.sum(0))
+        np.testing.assert_allclose(position_gradient(), want, rtol=1e-5, atol=1e-6, err_msg=refresh)
+
+
 @pytest.mark.parametrize("rows,width,inner", [((8, 128), 128, 512), ((3, 10), 36, 52), ((70,), 64, 64)])
 def test_feed_forward_block_against_the_separate_ops(hip, rows, width, inner):
     """dense2(gelu(dense1(x))) + x as one node (gelu and its derivative in GEMM epilogues) against Linear, gelu, Linear, add

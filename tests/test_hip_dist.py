@@ -23,6 +23,40 @@ def _run(spawn_ranks, tmp_path, *flags, env=None, wait_for_all=False, timeout=30
     return res
 
 
+def _check_reduced_gradient_against_float64(r0, r1, w0, g_cat32, floor=1e-5):
+    """the bucket after the exchange against the gradient of the concatenated batch formed in float64 (the oracle's code on float64
+    copies of the same float32 inputs): relative Frobenius <= 1e-5, or no further from it than twice the float32 oracle is"""
+    import np_oracle as O
+    from common import rel_frobenius
+    x = np.concatenate([r0["x"], r1["x"]]).astype(np.float64)
+    t = np.concatenate([r0["onehot"], r1["onehot"]]).astype(np.float64)
+    _, g64, _ = O.mlp_loss_and_grads({n: a.astype(np.float64) for n, a in w0.items()}, x, t)
+    for n in O.PARAM_ORDER:
+        assert g64[n].dtype == np.float64
+        e, e32 = rel_frobenius(r0["g/" + n], g64[n]), rel_frobenius(g_cat32[n], g64[n])
+        assert e <= max(floor, 2 * e32), "reduced gradient %s: %.3g from float64 (float32 oracle: %.3g)" % (n, e, e32)
+    return g64
+
+
+def _check_first_update_against_float64(r0, w0, g_cat32, g64):
+    """w1 - w0 after the first step == AdaBelief's update for SUM x 1/world.  The difference of two float32 weights carries their
+    rounding (half an ulp of the WEIGHT each, not of the update), so the yardstick for "as good as float32 gets" is the float32
+    oracle's update pushed through float32 weights the same way"""
+    import np_oracle as O
+    from common import rel_frobenius
+    opt64, opt32 = O.AdamState(1e-3, belief=True, eps=0.05), O.AdamState(1e-3, belief=True, eps=0.05)
+    d_mean = {}
+    for n in O.PARAM_ORDER:
+        d64 = opt64.delta(n, g64[n] * 0.5)
+        d32 = opt32.delta(n, g_cat32[n] * np.float32(0.5))
+        d_mean[n] = d32
+        assert d64.dtype == np.float64
+        got = r0["w1/" + n].astype(np.float64) - w0[n]
+        e, e32 = rel_frobenius(got, d64), rel_frobenius((w0[n] + d32).astype(np.float64) - w0[n], d64)
+        assert e <= max(1e-5, 2 * e32), "first update %s: %.3g from float64 (float32 oracle through float32 weights: %.3g)" % (n, e, e32)
+    return d_mean
+
+
 def _check_training(tmp_path, reduced_tolerance=1e-5):
     import np_oracle as O
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
@@ -37,13 +71,12 @@ def _check_training(tmp_path, reduced_tolerance=1e-5):
     _, g_cat, _ = O.mlp_loss_and_grads(w0, x, t)
     for n in O.PARAM_ORDER:
         np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=reduced_tolerance, atol=1e-6, err_msg=n)
-    opt = O.AdamState(1e-3, belief=True, eps=0.05)
-    d_mean = {n: opt.delta(n, g_cat[n] * np.float32(0.5)) for n in O.PARAM_ORDER}
+    g64 = _check_reduced_gradient_against_float64(r0, r1, w0, g_cat, floor=max(1e-5, reduced_tolerance))
+    d_mean = _check_first_update_against_float64(r0, w0, g_cat, g64)
     opt_sum = O.AdamState(1e-3, belief=True, eps=0.05)
     d_sum = {n: opt_sum.delta(n, g_cat[n]) for n in O.PARAM_ORDER}
-    for n in O.PARAM_ORDER:
+    for n in O.PARAM_ORDER:                                             # ... and clearly not SUM
         got = r0["w1/" + n].astype(np.float64) - w0[n]
-        np.testing.assert_allclose(got, d_mean[n], rtol=2e-3, atol=1e-8, err_msg=n)
         assert np.abs(got - d_sum[n]).max() > 20 * np.abs(got - d_mean[n]).max(), n
     assert not np.array_equal(r0["losses"], r1["losses"])               # different batches per rank
     return r0, r1
@@ -103,9 +136,9 @@ def test_exchange_at_mnist_mlp_size_in_a_replayed_graph(spawn_ranks, tmp_path):
     import np_oracle as O
     w0 = {n: r0["w0/" + n] for n in O.PARAM_ORDER}
     _, g_cat, _ = O.mlp_loss_and_grads(w0, np.concatenate([r0["x"], r1["x"]]), np.concatenate([r0["onehot"], r1["onehot"]]))
-    for n in O.PARAM_ORDER:           # SUM over the ranks == gradient of the concatenated 2048-sample batch
-        scale = np.abs(g_cat[n]).max()
-        np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * scale, err_msg=n)
+    # SUM over the ranks == gradient of the concatenated 2048-sample batch: against the oracle evaluated in FLOAT64 on the same
+    # float32 inputs, whole arrays, at the north star's 1e-5 (relative Frobenius); two float32 results can only be compared loosely
+    _check_reduced_gradient_against_float64(r0, r1, w0, g_cat)
 
 
 def test_exchange_of_a_bucket_beyond_448_chunks(spawn_ranks, tmp_path):
@@ -120,12 +153,8 @@ def test_exchange_of_a_bucket_beyond_448_chunks(spawn_ranks, tmp_path):
             np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
     w0 = {n: r0["w0/" + n] for n in O.PARAM_ORDER}
     _, g_cat, _ = O.mlp_loss_and_grads(w0, np.concatenate([r0["x"], r1["x"]]), np.concatenate([r0["onehot"], r1["onehot"]]))
-    for n in O.PARAM_ORDER:
-        np.testing.assert_allclose(r0["g/" + n], g_cat[n], rtol=1e-4, atol=1e-5 * np.abs(g_cat[n]).max(), err_msg=n)
-    opt = O.AdamState(1e-3, belief=True, eps=0.05)
-    for n in O.PARAM_ORDER:
-        got = r0["w1/" + n].astype(np.float64) - w0[n]
-        np.testing.assert_allclose(got, opt.delta(n, g_cat[n] * np.float32(0.5)), rtol=5e-3, atol=1e-8, err_msg=n)
+    g64 = _check_reduced_gradient_against_float64(r0, r1, w0, g_cat)
+    _check_first_update_against_float64(r0, w0, g_cat, g64)
 
 
 @pytest.mark.parametrize("world,window", [(2, 1 << 16), (4, 1 << 16), (2, 1 << 21)], ids=["two_ranks", "four_ranks", "two_ranks_several_pieces_per_workgroup"])

@@ -6,6 +6,17 @@ import lightgrad_amd as light
 from conftest import load_golden
 import np_oracle as O
 from test_cpu_backend import MLP
+from common import mlp_trajectory_on_cpu, assert_as_close_to_float64_as_the_cpu_backend
+
+
+def judged_by_float64(model, g, opt_name, steps, what):
+    """the trained weights against a float64 run of the same tape (tests/common.py): as close to it as the reference's float32 run"""
+    onehot = np.zeros((int(g["config"][3]), int(g["config"][2])), np.float32)
+    onehot[np.arange(onehot.shape[0]), g["labels"]] = 1
+    cls = {"adabelief": light.optim.AdaBelief, "adam": light.optim.Adam}[opt_name]
+    _, ref64 = mlp_trajectory_on_cpu({n: g["w0/" + n] for n in O.PARAM_ORDER}, g["x"], onehot, steps, lambda params: cls(params, lr=1e-3), np.float64)
+    assert_as_close_to_float64_as_the_cpu_backend({n: p.numpy() for n, p in model.named_parameters()}, {n: g["wf/" + n] for n in O.PARAM_ORDER},
+                                                  ref64, what=what)
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +49,7 @@ def test_device_step_counter_equals_host_scalars(hip, opt_name):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    judged_by_float64(model, g, opt_name, steps, "device step counter")
     assert opt.t == steps * 4 and int(opt._step_counter.numpy()[0]) == steps
 
 
@@ -57,6 +69,7 @@ def test_graph_replay_reproduces_reference_trajectory(hip):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    judged_by_float64(model, g, "adabelief", steps, "graph replay")
     assert opt.t == steps * 4
     before = HipDevice.pool_stats()["in_use_bytes"]
     graph.destroy()
@@ -138,6 +151,7 @@ def test_graphed_step_helper(hip):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    judged_by_float64(model, g, "adabelief", steps, "GraphedStep")
     assert opt.t == steps * 4
     graphed.destroy()
 

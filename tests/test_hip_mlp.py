@@ -7,6 +7,7 @@ from lightgrad_amd import CpuTensor
 from conftest import load_golden
 import np_oracle as O
 from test_cpu_backend import MLP, train
+from common import mlp_trajectory_on_cpu, assert_as_close_to_float64_as_the_cpu_backend
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +31,12 @@ def test_small_trajectory_vs_reference(hip, opt_name):
     for n, p in model.named_parameters():
         assert isinstance(p, hip)
         np.testing.assert_allclose(g0[n], g["g0/" + n], rtol=1e-5, atol=1e-6, err_msg=n)
-        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+        np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)      # two float32 runs: loose by nature ...
+    # ... so the trained weights are judged by the float64 run of the same tape: as close to it as the reference's float32 result
+    w0 = {n: g["w0/" + n] for n in O.PARAM_ORDER}
+    _, ref64 = mlp_trajectory_on_cpu(w0, g["x"], onehot, steps, lambda params: make_opt(opt_name, params), np.float64)
+    assert_as_close_to_float64_as_the_cpu_backend({n: p.numpy() for n, p in model.named_parameters()}, {n: g["wf/" + n] for n in O.PARAM_ORDER},
+                                                  ref64, what=opt_name)
 
 
 def test_full_size_trajectory_vs_reference(hip):
@@ -56,6 +62,12 @@ def test_full_size_trajectory_vs_reference(hip):
         np.testing.assert_allclose(sample(p.numpy()), g["wfsample/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
         w = p.numpy().astype(np.float64)
         np.testing.assert_allclose([w.sum(), np.abs(w).sum()], g["wfsum/" + n], rtol=1e-4, atol=1e-3)
+    # the five-step trajectory against a float64 run of the same tape: WHOLE weight arrays, and the losses at 1e-5
+    make = lambda params: make_opt("adabelief", params)      # noqa: E731
+    losses64, ref64 = mlp_trajectory_on_cpu(w0, x, onehot, steps, make, np.float64)
+    _, cpu32 = mlp_trajectory_on_cpu(w0, x, onehot, steps, make, np.float32)
+    np.testing.assert_allclose(losses, losses64, rtol=1e-5)
+    assert_as_close_to_float64_as_the_cpu_backend({n: p.numpy() for n, p in model.named_parameters()}, cpu32, ref64, what="full size")
 
 
 def test_step_gradients_vs_oracle_on_fresh_seed(hip):
@@ -86,3 +98,7 @@ def test_fused_optimizer_equals_tape_form(hip, opt_name):
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-5)
     for n, p in model.named_parameters():
         np.testing.assert_allclose(p.numpy(), g["wf/" + n], rtol=1e-4, atol=2e-6, err_msg=n)
+    w0 = {n: g["w0/" + n] for n in O.PARAM_ORDER}
+    _, ref64 = mlp_trajectory_on_cpu(w0, g["x"], onehot, steps, lambda params: make_opt(opt_name, params), np.float64)
+    assert_as_close_to_float64_as_the_cpu_backend({n: p.numpy() for n, p in model.named_parameters()}, {n: g["wf/" + n] for n in O.PARAM_ORDER},
+                                                  ref64, what="fused " + opt_name)

@@ -171,6 +171,26 @@ int lg_reduce(int op, int ndim, const int64_t* shape,
               const void* in, const int64_t* in_strides,
               uint32_t axis_mask, void* out);
 
+/* ---- tensors that are not float32 (round 4) -----------------------------------
+ * The reference's tensors keep whatever dtype their numpy array has (cpu/tensor.py:45-46: MNIST labels int16, data.py:43; BERT
+ * ids int32, examples/bert.py:346) and its device backend generates every elementwise / reduction kernel per dtype
+ * (opencl/kernels.py:9, :24-107, :344-431).  Here float32 - the north-star path - has its own tuned kernels (lg_ew, lg_reduce);
+ * these entry points make int16 / int32 / int64 / float64 tensors computable on the device with numpy's semantics
+ * (cpu/ops.py:52-84, :260-293): integers wrap around, integer sums are int64, max / min keep the dtype and propagate NaN.
+ *   lg_ew_typed      out = a (op) b, all three of `dtype`, numpy broadcasting through strides; op = LG_EW_COPY / NEG (unary),
+ *                    ADD / SUB / MUL, and for float64 DIV / POW; a NULL operand is the scalar (scalar_i for integers, scalar_f
+ *                    for float64); out may alias an operand element for element (in-place forms)
+ *   lg_reduce_typed  as lg_reduce; `out` holds int64 for integer sums, `dtype` otherwise
+ *   lg_cast          out[i] = (dst type) in[i], any pair of the five dtypes (numpy's astype: float -> int truncates) */
+typedef enum { LG_DT_I16 = 1, LG_DT_I32 = 2, LG_DT_I64 = 3, LG_DT_F64 = 4, LG_DT_F32 = 5 } lg_dtype_t;
+int lg_ew_typed(int op, int dtype, int ndim, const int64_t* shape, void* out, const int64_t* out_strides,
+                const void* a, const int64_t* a_strides, const void* b, const int64_t* b_strides,
+                double scalar_f, int64_t scalar_i);
+int lg_reduce_typed(int op, int dtype, int ndim, const int64_t* shape, const void* in, const int64_t* in_strides,
+                    uint32_t axis_mask, void* out);
+int lg_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* shape, void* out, const int64_t* out_strides,
+            const void* in, const int64_t* in_strides);
+
 /* out (+)= reduction: with accumulate != 0 (sums only) the result is ADDED to `out`, so a bias gradient
  * can be accumulated straight into its gradient buffer (tensor.py:118 `grad += g` without the extra pass). */
 int lg_reduce_acc(int op, int ndim, const int64_t* shape,
@@ -359,6 +379,16 @@ int lg_put_axis(int itemsize, void* dst, int64_t outer, int64_t axis_len, int64_
                 const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const void* val, uint64_t scalar_bits);
 int lg_scatter_add_axis_f32(float* dst, int64_t outer, int64_t axis_len, int64_t inner,
                             const void* idx, int idx_itemsize, int64_t n_idx, int64_t pair_period, const float* src);
+
+/* Several index arrays / plain integers of one subscript folded into ONE flat index on the device (round 4): out[e] = the
+ * row-major position of (idx_0[e], ..., idx_{k-1}[e]) in axes of lengths lens[0..k), e running over the arrays' common broadcast
+ * `shape` (idx_strides[j][d] = stride of array j along broadcast dimension d in elements, 0 where it is broadcast; idx[j] NULL:
+ * the plain integer constants[j]).  Negative indices count from the end; one out of range raises the device status flag like
+ * the kernels above.  lg_mask_nonzero: the flat positions of the non-zero bytes of a boolean mask of n elements, ascending
+ * (room for n), and their number - the one value a caller has to read back (it is the length of the result). */
+int lg_index_fold(int k, const int64_t* lens, const void* const* idx, const int* idx_itemsize, const int64_t* constants,
+                  int ndim, const int64_t* shape, const int64_t* const* idx_strides, int64_t* out);
+int lg_mask_nonzero(const void* mask, int64_t n, int64_t* out_positions, int64_t* out_count);
 
 /* ---- self-attention of a short sequence, one launch each way (csrc/attention.hip) ------------------------
  * Per (batch, head): P = softmax((Q K^T) * scale), O = P V (reference examples/bert.py:78-88: scores GEMM, `/ sqrt(d)`,

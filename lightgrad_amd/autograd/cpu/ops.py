@@ -54,6 +54,21 @@ def _op(*names, overwrite=False):
 """ Transformations """
 
 
+@_op("astype")
+class astype(Function):
+    """ t.astype(dtype) - not an op of the reference (its tensors change dtype through numpy on the host, cpu/tensor.py:12);
+    here so that code written for HipTensor.astype runs on the CPU backend too.  Differentiable between float dtypes. """
+    def forward(ctx, a, dtype=np.float32):
+        ctx.save_for_backward(a.dtype, np.dtype(dtype))
+        return a.astype(dtype)
+
+    def backward(ctx, out_grad):
+        src, dst = ctx.get_saved_tensors()
+        if src.kind != "f" or dst.kind != "f":
+            raise RuntimeError("Cannot Backward through astype(%s -> %s)!" % (src, dst))
+        return out_grad.astype(src)
+
+
 @_op("T", "transpose")
 class transpose(Function):
     """ axis permutation view; backward = inverse permutation (cpu/ops.py:25-36) """

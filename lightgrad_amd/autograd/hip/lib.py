@@ -21,6 +21,8 @@ EW_COPY, EW_NEG, EW_EXP, EW_LOG, EW_RELU, EW_SIGMOID, EW_TANH, EW_SIN, EW_COS, E
 EW_MAX_BWD, EW_FMA = 64, 65
 EW_MUL_BWD, EW_DIV_BWD, EW_POW_BWD = 96, 97, 98
 RED_SUM, RED_MAX, RED_MIN = 0, 1, 2
+# lg_dtype_t (lghip.h): the dtypes lg_ew_typed / lg_reduce_typed / lg_cast know
+DT_I16, DT_I32, DT_I64, DT_F64, DT_F32 = 1, 2, 3, 4, 5
 
 
 class DeviceInfo(ctypes.Structure):
@@ -65,6 +67,9 @@ PROTOTYPES = {
     "lg_ew": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P,
                       c_void_p, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_float]),
     "lg_reduce": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p]),
+    "lg_ew_typed": (c_int, [c_int, c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_void_p, _I64P, c_double, c_int64]),
+    "lg_reduce_typed": (c_int, [c_int, c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p]),
+    "lg_cast": (c_int, [c_int, c_int, c_int, _I64P, c_void_p, _I64P, c_void_p, _I64P]),
     "lg_reduce_acc": (c_int, [c_int, c_int, _I64P, c_void_p, _I64P, c_uint32, c_void_p, c_int]),
     "lg_gemm_f32": (c_int, [c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
@@ -123,6 +128,8 @@ PROTOTYPES = {
     "lg_take_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     "lg_put_axis": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p, c_uint64]),
     "lg_scatter_add_axis_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "lg_index_fold": (c_int, [c_int, _I64P, POINTER(c_void_p), POINTER(c_int), _I64P, c_int, _I64P, POINTER(_I64P), c_void_p]),
+    "lg_mask_nonzero": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "lg_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),
     "lg_gather_sum3_rows_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64] * 3 + [c_int, c_void_p, c_int64, c_int64]),
     "lg_scatter_add_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64]),

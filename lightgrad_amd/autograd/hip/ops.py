@@ -70,14 +70,83 @@ def _ew(op, shape, ins, scalar=0.0, n_out=1, out=None):
     return outs[0] if len(outs) == 1 else tuple(outs)
 
 
+# ---- tensors that are not float32 (csrc/typed.hip) --------------------------------------------------------------------
+# The reference's tensors keep their numpy dtype (cpu/tensor.py:45-46; labels int16, ids int32) and numpy computes with
+# whatever it is given (cpu/ops.py:52-84).  float32 has the tuned kernels; int16 / int32 / int64 / float64 go through
+# lg_ew_typed / lg_reduce_typed with numpy's semantics (wrap-around integers, int64 sums) for neg, add, sub, mul (float64: also
+# div, pow), their in-place forms, sum / max / min, and `astype`.  Two tensor operands must share a dtype - numpy would
+# promote, here a cast is asked for explicitly (`.astype`).
+_TYPED = {np.dtype(np.int16): _l.DT_I16, np.dtype(np.int32): _l.DT_I32, np.dtype(np.int64): _l.DT_I64, np.dtype(np.float64): _l.DT_F64}
+_CASTABLE = dict(_TYPED)
+_CASTABLE[_F32] = _l.DT_F32
+_TYPED_OPS_INT = (_l.EW_COPY, _l.EW_NEG, _l.EW_ADD, _l.EW_SUB, _l.EW_MUL)
+_TYPED_OPS_F64 = _TYPED_OPS_INT + (_l.EW_DIV, _l.EW_POW)
+_F64 = np.dtype(np.float64)
+
+
+def _operand_dtype(*operands):
+    """the dtype shared by the tensor operands (scalars do not count); TypeError when they differ"""
+    dt = None
+    for t in operands:
+        if isinstance(t, HipTensor):
+            if dt is not None and t._dtype != dt:
+                raise TypeError("HipTensor operands of different dtypes (%s, %s): cast one of them with .astype() first" % (dt, t._dtype))
+            dt = t._dtype
+    return dt
+
+
+def _ew_typed(op, dt, shape, a, b, out=None):
+    """a (op) b for int16 / int32 / int64 / float64 tensors; a or b may be a python / numpy scalar (None for unary ops)"""
+    code = _TYPED.get(dt)
+    if code is None or op not in (_TYPED_OPS_F64 if dt == _F64 else _TYPED_OPS_INT):
+        raise TypeError("HipTensor: this operation is not defined for dtype %s (float32 everywhere; int16 / int32 / int64 / float64: "
+                        "neg, add, sub, mul, sum, max, min, astype, and for float64 div and pow)" % dt)
+    if out is not None:
+        assert out._dtype == dt
+        flush_lazy_readers(out)
+    else:
+        out = HipTensor.empty(shape, dtype=dt)
+    scalar = next((x for x in (a, b) if x is not None and not isinstance(x, HipTensor)), 0)
+    ptrs = []
+    for t in (a, b):
+        ptrs += [t.ptr, i64(_bstrides(t, shape))] if isinstance(t, HipTensor) else [_NULL, _NULL]
+    _l.check(_l.lib().lg_ew_typed(op, code, len(shape), i64(shape), out.ptr, i64(out._strides), *ptrs,
+                                  float(scalar), int(scalar) if dt != _F64 else 0))
+    return out
+
+
+def _cast(t, dtype):
+    """t.astype(dtype) as a new dense tensor (numpy's conversion rules: float -> int truncates toward zero)"""
+    dtype = np.dtype(dtype)
+    if dtype not in _CASTABLE or t._dtype not in _CASTABLE:
+        raise TypeError("HipTensor.astype: %s -> %s (int16, int32, int64, float32, float64)" % (t._dtype, dtype))
+    out = HipTensor.empty(t._shape, dtype=dtype, requires_grad=False)
+    _l.check(_l.lib().lg_cast(_CASTABLE[t._dtype], _CASTABLE[dtype], len(t._shape), i64(t._shape), out.ptr, i64(out._strides),
+                              t.ptr, i64(t._strides)))
+    return out
+
+
 def _unary(op, t):
-    _require_f32(t)
+    if t._dtype != _F32:
+        return _ew_typed(op, t._dtype, t._shape, t, None)
     return _ew(op, t._shape, [t])
 
 
 def _binary(op, a, b, out=None):
     """a (op) b with numpy broadcasting; either operand (not both) may be a python/numpy scalar"""
-    _require_f32(a, b)
+    dt = _operand_dtype(a, b)
+    if dt != _F32 and dt is not None:
+        scalar = b if _is_scalar(b) else (a if _is_scalar(a) else None)
+        if dt != _F64 and scalar is not None and not isinstance(scalar, (int, np.integer)):
+            # an integer tensor meets a float scalar: numpy computes in float64 (a python float is "weak" only among floats)
+            if out is not None:
+                raise TypeError("in-place operation of an %s tensor with a float scalar: the result is float64 and does not fit" % dt)
+            a = _cast(a, _F64) if isinstance(a, HipTensor) else a
+            b = _cast(b, _F64) if isinstance(b, HipTensor) else b
+            dt = _F64
+        tensors = [t for t in (a, b) if isinstance(t, HipTensor)]
+        shape = tensors[0]._shape if len(tensors) == 1 or tensors[0]._shape == tensors[1]._shape else _broadcast_shapes(*(t._shape for t in tensors))
+        return _ew_typed(op, dt, shape, a, b, out=out)
     if _is_scalar(b):
         return _ew(op, a._shape, [a, None], scalar=b, out=out)
     if _is_scalar(a):
@@ -200,6 +269,8 @@ class mul(Function):
             return _binary(_l.EW_MUL, out_grad, b)
         if _is_scalar(a):
             return None, _binary(_l.EW_MUL, out_grad, a)
+        if out_grad._dtype != _F32:              # float64 tapes: the two products as two kernels (g * b, a * g: cpu/ops.py:83-84)
+            return _binary(_l.EW_MUL, out_grad, b), _binary(_l.EW_MUL, a, out_grad)
         _require_f32(a, b, out_grad)
         shape = _broadcast_shapes(a._shape, b._shape, out_grad._shape)
         return _ew(_l.EW_MUL_BWD, shape, [a, b, out_grad], n_out=2)
@@ -220,6 +291,9 @@ class div(Function):
             # -a / b**2 * g, evaluated left to right like the numpy expression
             t = _binary(_l.EW_DIV, -float(a), _binary(_l.EW_MUL, b, b))
             return None, _binary(_l.EW_MUL, t, out_grad)
+        if out_grad._dtype != _F32:              # float64: g / b and -a / b**2 * g, left to right like cpu/ops.py:93-94
+            return (_binary(_l.EW_DIV, out_grad, b),
+                    _binary(_l.EW_MUL, _binary(_l.EW_DIV, _unary(_l.EW_NEG, a), _binary(_l.EW_MUL, b, b)), out_grad))
         _require_f32(a, b, out_grad)
         shape = _broadcast_shapes(a._shape, b._shape, out_grad._shape)
         return _ew(_l.EW_DIV_BWD, shape, [a, b, out_grad], n_out=2)
@@ -641,6 +715,21 @@ def _inplace(op, t, other):
     return _alias(t)
 
 
+@HipTensor.register_op()
+class astype(Function):
+    """ t.astype(dtype): numpy's conversion (the reference has no cast op: its tensors change dtype through numpy on the host,
+    cpu/tensor.py:12).  Differentiable between float dtypes: the gradient is cast back. """
+    def forward(ctx, t, dtype=np.float32):
+        ctx.save_for_backward(t._dtype, np.dtype(dtype))
+        return _cast(t, dtype) if np.dtype(dtype) != t._dtype else _unary(_l.EW_COPY, t)
+
+    def backward(ctx, out_grad):
+        src, dst = ctx.get_saved_tensors()
+        if src.kind != "f" or dst.kind != "f":
+            raise RuntimeError("Cannot Backward through astype(%s -> %s)!" % (src, dst))
+        return _cast(out_grad, src) if out_grad._dtype != src else out_grad
+
+
 @HipTensor.register_op("__iadd__", overwrite=True)
 class iadd(Function):
     def forward(ctx, t, other):
@@ -744,14 +833,7 @@ def _is_advanced(i):
 class _TakePlan(object):
     """integer-array indexing split into a basic view + ONE gather along an axis of that view (csrc/index.hip).  `merge` > 1:
     the gather runs along that many neighbouring axes of the (dense) view taken as one axis, with row-major flat indices"""
-    __slots__ = ("basic", "axis", "index", "pair", "merge")
-
-
-def _host_index(x):
-    """an index array on the host (device-resident ones are read back: their VALUES decide shapes or flat positions here)"""
-    if isinstance(x, HipTensor):
-        return x.numpy()
-    return np.asarray(list(x)) if isinstance(x, range) else np.asarray(x)
+    __slots__ = ("basic", "axis", "index", "pair", "merge", "perm")
 
 
 def _is_bool_index(i):
@@ -785,96 +867,147 @@ def _is_arange(x, n):
     return arr.ndim == 1 and arr.shape[0] == n and arr.dtype.kind in "iu" and np.array_equal(arr, np.arange(n))
 
 
+def _mask_positions(mask, dims):
+    """flat row-major positions of the True elements of a boolean mask over axes of lengths `dims` (numpy: x[mask] ==
+    x[mask.nonzero()]), as a dense int64 device tensor of shape (count,).  A host mask is searched on the host; a device mask on
+    the device (lg_mask_nonzero) - only the COUNT comes back, because the result's shape depends on it."""
+    shape = mask._shape if isinstance(mask, HipTensor) else np.asarray(mask).shape
+    if tuple(shape) != tuple(dims):
+        raise IndexError("boolean index did not match indexed array: mask of shape %s on dimensions of shape %s" % (tuple(shape), tuple(dims)))
+    if not isinstance(mask, HipTensor):
+        flat = np.flatnonzero(np.asarray(mask, dtype=np.bool_))
+        return HipTensor.from_numpy(flat.astype(np.int64), requires_grad=False)
+    m = mask.contiguous()
+    n = m.numel()
+    positions = HipTensor.empty((_py.max(n, 1),), dtype=np.int64, requires_grad=False)
+    count = HipTensor.empty((1,), dtype=np.int64, requires_grad=False)
+    _l.check(_l.lib().lg_mask_nonzero(m.ptr, n, positions.ptr, count.ptr))
+    k = int(count.numpy()[0])                                   # the one read-back: the length of the result
+    return HipTensor(positions.data, (k,), None, positions._offset, positions._dtype, requires_grad=False)
+
+
+def _fold_indices(groups, bshape):
+    """ONE flat row-major index over the axes the advanced indices of a subscript cover, on the device (lg_index_fold).
+    groups: [(length the index runs over, dense device index tensor | python int)]; bshape: the arrays' broadcast shape"""
+    k, nd = len(groups), len(bshape)
+    out = HipTensor.empty(bshape, dtype=np.int64, requires_grad=False)
+    lens = i64(tuple(int(g[0]) for g in groups))
+    ptrs = (ctypes.c_void_p * k)(*[g[1].ptr if isinstance(g[1], HipTensor) else None for g in groups])
+    sizes = (ctypes.c_int * k)(*[g[1]._dtype.itemsize if isinstance(g[1], HipTensor) else 8 for g in groups])
+    consts = i64(tuple(0 if isinstance(g[1], HipTensor) else int(g[1]) for g in groups))
+    strides = [i64(_bstrides(g[1], bshape)) if isinstance(g[1], HipTensor) else i64((0,) * _py.max(nd, 1)) for g in groups]
+    stride_ptrs = (ctypes.POINTER(ctypes.c_int64) * k)(*[ctypes.cast(st, ctypes.POINTER(ctypes.c_int64)) for st in strides])
+    _l.check(_l.lib().lg_index_fold(k, lens, ptrs, sizes, consts, nd, i64(tuple(bshape)), stride_ptrs, out.ptr))
+    return out
+
+
 def _take_plan(a, idx):
-    """None for basic indexing, else the _TakePlan of `a[idx]`.  Supported: any mix of ints / slices / Ellipsis / None with ONE
-    integer-array index (any shape), or with the pair `range(n), labels` on two neighbouring axes (loss.py:19)."""
+    """None for basic indexing, else the _TakePlan of `a[idx]`: what numpy does with a subscript that holds index arrays or
+    boolean masks (cpu/ops.py:234-255 hands it to numpy).  ONE index array next to ints / slices and the pair `range(n), labels`
+    (loss.py:19) gather straight along their axis; everything else - several arrays broadcast together, masks over any run of
+    axes, plain integers among them, arrays on NON-neighbouring axes (numpy then moves the index dimensions to the front) - is
+    folded on the device into one flat index over the covered axes, which are brought together by a transposed view first."""
     idx = idx if isinstance(idx, tuple) else (idx,)
-    adv = [k for k, i in enumerate(idx) if _is_advanced(i)]
-    if not adv:
+    if not any(_is_advanced(i) for i in idx):
         return None
-    if any(_is_bool_index(idx[k]) for k in adv):
-        # a boolean mask selects where it is True: numpy's x[mask] == x[mask.nonzero()] - one index array per axis the mask spans
-        # (cpu/ops.py:234-255 hands the mask to numpy).  The result's SIZE depends on the mask's values: read it back.
-        expanded = []
-        for i in idx:
-            if _is_advanced(i) and _is_bool_index(i):
-                expanded.extend(np.nonzero(_host_index(i).astype(np.bool_)) + (_MaskShape(_host_index(i).shape),))
-            else:
-                expanded.append(i)
-        idx, masks = [], []
-        for i in expanded:
-            if isinstance(i, _MaskShape):
-                masks.append((len(idx) - len(i.shape), i.shape))          # position of the mask's first index array, its shape
-            else:
-                idx.append(i)
-        idx = tuple(idx)
-        adv = [k for k, i in enumerate(idx) if _is_advanced(i)]
-    else:
-        masks = []
-    if len(adv) > 1 and adv[-1] - adv[0] != len(adv) - 1:
-        raise NotImplementedError("HipTensor indexing: index arrays must sit on neighbouring axes (numpy moves the result dimensions "
-                                  "of separated index arrays to the front; not built)")
+    n_real = 0
+    for i in idx:
+        if i is None or i is Ellipsis:
+            continue
+        n_real += len(i._shape if isinstance(i, HipTensor) else np.asarray(i).shape) if _is_advanced(i) and _is_bool_index(i) else 1
+    if Ellipsis in idx:
+        k = idx.index(Ellipsis)
+        idx = idx[:k] + (slice(None),) * (len(a._shape) - n_real) + idx[k + 1:]
+    # where every entry lands: axis of `a` it starts at, kind
+    arrays = [i for i in idx if _is_advanced(i) and not _is_bool_index(i)]
+    masks = [i for i in idx if _is_advanced(i) and _is_bool_index(i)]
+    has_none = any(i is None for i in idx)
+    ints_count = [i for i in idx if not (i is None or isinstance(i, slice) or _is_advanced(i))]
+    # positions (among the non-None entries) of everything numpy treats as an advanced index here: arrays, masks and plain ints
+    order = [i for i in idx if i is not None]
+    adv_pos = [k for k, i in enumerate(order) if _is_advanced(i) or not isinstance(i, slice)]
+    adjacent = adv_pos[-1] - adv_pos[0] == len(adv_pos) - 1
+
     plan = _TakePlan()
-    plan.merge = 1
-    plan.basic = tuple(slice(None) if _is_advanced(i) else i for i in idx)
-    # axis of the basic VIEW the first array index applies to: entries in front of it that produce a dimension
-    n_real = _py.sum(1 for i in idx if i is not None and i is not Ellipsis)
-    axis = 0
-    for i in idx[:adv[0]]:
-        if i is Ellipsis:
-            axis += len(a._shape) - n_real
-        elif i is None or isinstance(i, slice):
+    plan.merge, plan.pair, plan.perm = 1, False, None
+    if len(arrays) == 1 and not masks and (adjacent or not ints_count):
+        # one index array; ints next to it just drop their axes first (the result is the same as numpy's in-place rule)
+        plan.basic = tuple(slice(None) if _is_advanced(i) else i for i in idx)
+        axis = 0
+        for i in idx[:next(k for k, i in enumerate(idx) if _is_advanced(i))]:
+            if i is None or isinstance(i, slice):
+                axis += 1
+        plan.axis = axis
+        plan.index = _index_tensor(arrays[0], _idx_view(a, plan.basic)._shape[axis])
+        return plan
+    if has_none:
+        raise IndexError("HipTensor indexing: None (newaxis) together with several index arrays / masks is not supported - index first, reshape then")
+    first = next(k for k, i in enumerate(idx) if _is_advanced(i))
+    if (len(arrays) == 2 and not masks and not ints_count and adjacent):
+        view_shape = _idx_view(a, tuple(slice(None) if _is_advanced(i) else i for i in idx))._shape
+        axis = _py.sum(1 for i in idx[:first] if isinstance(i, slice))
+        if _is_arange(arrays[0], view_shape[axis]):
+            n = view_shape[axis]
+            plan.basic = tuple(slice(None) if _is_advanced(i) else i for i in idx)
+            plan.axis, plan.pair = axis, True
+            plan.index = _index_tensor(arrays[1], view_shape[axis + 1])
+            if plan.index._shape != (n,):
+                raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes (%d,) %s" % (n, plan.index._shape))
+            return plan
+    # ---- the general form.  Every advanced entry (array, mask, plain int) keeps its axes in the basic view; `groups` lists them
+    basic, groups, adv_axes, axis = [], [], [], 0
+    for i in idx:
+        if isinstance(i, slice):
+            basic.append(i)
             axis += 1
-    plan.axis = axis
-    view_shape = _idx_view(a, plan.basic)._shape
-    for pos, mshape in masks:
-        ax0 = axis + (pos - adv[0])
-        if tuple(view_shape[ax0:ax0 + len(mshape)]) != tuple(mshape):
-            raise IndexError("boolean index did not match indexed array: mask of shape %s on dimensions of shape %s"
-                             % (mshape, tuple(view_shape[ax0:ax0 + len(mshape)])))
-    if len(adv) == 1:
-        plan.pair = False
-        plan.index = _index_tensor(idx[adv[0]], view_shape[axis])
-    elif len(adv) == 2 and _is_arange(idx[adv[0]], view_shape[axis]) and not masks:
-        n = view_shape[axis]
-        plan.pair = True
-        plan.index = _index_tensor(idx[adv[1]], view_shape[axis + 1])
-        if plan.index._shape != (n,):
-            raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes (%d,) %s" % (n, plan.index._shape))
+        elif _is_advanced(i) and _is_bool_index(i):
+            m = len(i._shape if isinstance(i, HipTensor) else np.asarray(i).shape)
+            dims = a._shape[axis:axis + m]
+            length = 1
+            for dlen in dims:
+                length *= dlen
+            groups.append((length, _mask_positions(i, dims)))
+            adv_axes += list(range(axis, axis + m))
+            basic += [slice(None)] * m
+            axis += m
+        elif _is_advanced(i):
+            groups.append((a._shape[axis], _index_tensor(i, a._shape[axis])))
+            adv_axes.append(axis)
+            basic.append(slice(None))
+            axis += 1
+        else:
+            size, v = a._shape[axis], int(i)
+            if v < -size or v >= size:
+                raise IndexError("index %d is out of bounds for axis %d with size %d" % (v, axis, size))
+            groups.append((size, v))
+            adv_axes.append(axis)
+            basic.append(slice(None))
+            axis += 1
+    if axis > len(a._shape):
+        raise IndexError("too many indices for tensor: tensor is %d-dimensional, but %d were indexed" % (len(a._shape), axis))
+    plan.basic = tuple(basic)
+    try:
+        bshape = _broadcast_shapes(*[g[1]._shape for g in groups if isinstance(g[1], HipTensor)])
+    except ValueError:
+        raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes %s"
+                         % " ".join(str(g[1]._shape) for g in groups if isinstance(g[1], HipTensor)))
+    plan.index = _fold_indices(groups, bshape)
+    plan.merge = len(adv_axes)
+    if adjacent:
+        plan.axis = adv_axes[0]                   # the covered axes are neighbours: the index dimensions take their place
     else:
-        # several index arrays on neighbouring axes: broadcast together, validated and folded into ONE row-major flat index over
-        # those axes on the host (a device-resident index array is read back for it); the kernels then gather / scatter along the
-        # merged axis of the dense view
-        k = len(adv)
-        dims = tuple(view_shape[axis:axis + k])
-        arrays = []
-        for j, pos in enumerate(adv):
-            arr = _host_index(idx[pos])
-            if arr.dtype.kind not in "iu":
-                raise IndexError("arrays used as indices must be of integer (or boolean) type (got %s)" % arr.dtype)
-            arr = arr.astype(np.int64)
-            if arr.size and (arr.min() < -dims[j] or arr.max() >= dims[j]):
-                bad = arr[(arr < -dims[j]) | (arr >= dims[j])].flat[0]
-                raise IndexError("index %d is out of bounds for axis with size %d" % (bad, dims[j]))
-            arrays.append(np.where(arr < 0, arr + dims[j], arr))
-        try:
-            arrays = np.broadcast_arrays(*arrays)
-        except ValueError:
-            raise IndexError("shape mismatch: indexing arrays could not be broadcast together with shapes %s"
-                             % " ".join(str(x.shape) for x in arrays))
-        flat = np.ravel_multi_index(tuple(arrays), dims) if arrays[0].size else np.zeros(arrays[0].shape, np.int64)
-        plan.pair = False
-        plan.merge = k
-        plan.index = HipTensor.from_numpy(np.ascontiguousarray(flat, dtype=np.int64), requires_grad=False)
+        # numpy: index arrays separated by a slice -> the index dimensions go FIRST.  A transposed view brings the covered axes
+        # together at the front; the gather then runs along them as one axis
+        nd = len(a._shape)
+        plan.perm = tuple(adv_axes) + tuple(d for d in range(nd) if d not in adv_axes)
+        plan.axis = 0
     return plan
 
 
-class _MaskShape(object):
-    """marker left behind the index arrays a boolean mask was turned into (its shape is checked against the indexed axes)"""
-    __slots__ = ("shape",)
-
-    def __init__(self, shape):
-        self.shape = tuple(shape)
+def _plan_view(a, plan):
+    """the basic view a plan's gather / assignment / scatter-add works on (axes permuted when the index arrays were apart)"""
+    view = _idx_view(a, plan.basic)
+    return view if plan.perm is None else view.transpose(*plan.perm)
 
 
 def _take_extents(view_shape, plan):
@@ -890,7 +1023,7 @@ def _take_extents(view_shape, plan):
 
 
 def _take(a, plan):
-    src = _idx_view(a, plan.basic).contiguous()
+    src = _plan_view(a, plan).contiguous()
     outer, axis_len, inner, period, shape = _take_extents(src._shape, plan)
     out = HipTensor.empty(shape, dtype=a._dtype)
     _l.check(_l.lib().lg_take_axis(a._dtype.itemsize, src.ptr, outer, axis_len, inner, plan.index.ptr, plan.index._dtype.itemsize,
@@ -900,7 +1033,7 @@ def _take(a, plan):
 
 def _put(a, plan, val):
     """a[idx] = val for a plan: in place when the basic view is dense, else through a dense copy of the view"""
-    view = _idx_view(a, plan.basic)
+    view = _plan_view(a, plan)
     dense = view if view.is_contiguous() else view.contiguous()
     outer, axis_len, inner, period, shape = _take_extents(dense._shape, plan)
     bits, vptr = 0, None
@@ -926,7 +1059,7 @@ def _put(a, plan, val):
 
 def _scatter_add(grad, plan, out_grad):
     """grad[idx] += out_grad for a plan (fp32); `grad` is a dense tensor of the indexed tensor's shape"""
-    view = _idx_view(grad, plan.basic)
+    view = _plan_view(grad, plan)
     g = out_grad.contiguous()
     if view.is_contiguous():
         outer, axis_len, inner, period, shape = _take_extents(view._shape, plan)
@@ -1150,13 +1283,20 @@ def _reduce_into(acc, x, axes, overwrite=False):
 
 
 def _reduce(op, x, axes, keepdims):
-    _require_f32(x)
     mask = 0
     for a in axes:
         mask |= 1 << a
     kept = tuple(s for i, s in enumerate(x._shape) if i not in axes)
-    out = HipTensor.empty(kept)
-    _l.check(_l.lib().lg_reduce(op, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, out.ptr))
+    if x._dtype != _F32:
+        code = _TYPED.get(x._dtype)
+        if code is None:
+            raise TypeError("HipTensor reductions: dtype %s (float32, float64, int16, int32, int64)" % x._dtype)
+        # numpy: the sum of int16 / int32 values is formed - and returned - in int64; max / min keep the dtype
+        out = HipTensor.empty(kept, dtype=np.int64 if (op == _l.RED_SUM and x._dtype != _F64) else x._dtype)
+        _l.check(_l.lib().lg_reduce_typed(op, code, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, out.ptr))
+    else:
+        out = HipTensor.empty(kept)
+        _l.check(_l.lib().lg_reduce(op, len(x._shape), i64(x._shape), x.ptr, i64(x._strides), mask, out.ptr))
     if keepdims:
         full = tuple(1 if i in axes else s for i, s in enumerate(x._shape))
         out = HipTensor(out.data, full, None, out._offset, out._dtype)

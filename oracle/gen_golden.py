@@ -293,6 +293,99 @@ def main():
     fi2["put_mask_scalar/in"], fi2["put_mask_scalar/mask"], fi2["put_mask_scalar/out"] = a, m2, np.array(t.numpy())
     np.savez_compressed(os.path.join(OUT, "fancy_index_multi.npz"), **fi2)
 
+    # ---------------------------------------------------------------- round 4: index arrays on NON-neighbouring axes (numpy moves
+    # the index dimensions to the front), plain integers among index arrays (numpy counts them as index arrays for that rule), a
+    # mask next to an index array - all through the reference's CPU path (cpu/ops.py:234-255).  Unique index tuples (see above).
+    fi3 = {}
+    rng6 = np.random.RandomState(4242)
+
+    def run_apart(name, shape, make_index, arrays):
+        a = f32(rng6, -1, 1, shape)
+        t = T.from_numpy(a.copy())
+        y = t[make_index(lambda v: T.from_numpy(v, requires_grad=False))]
+        w = f32(rng6, -1, 1, y.shape)
+        (y * T.from_numpy(w, requires_grad=False)).backward(allow_fill=True)
+        fi3[name + "/in"], fi3[name + "/out"], fi3[name + "/w"], fi3[name + "/grad"] = a, np.array(y.numpy()), w, np.array(t.grad.numpy())
+        for k, v in arrays.items():
+            fi3["%s/%s" % (name, k)] = v
+    flat = rng6.permutation(4 * 6)[:5]
+    ia, ib = (flat // 6).astype(np.int64), (flat % 6).astype(np.int32)
+    run_apart("arrays_apart", (4, 5, 6), lambda D: (D(ia), slice(None), D(ib)), {"i0": ia, "i1": ib})
+    run_apart("arrays_apart_4d", (4, 3, 6, 2), lambda D: (D(ia), slice(1, 3), D(ib)), {"i0": ia, "i1": ib})
+    ic = rng6.permutation(6)[:4].astype(np.int64)
+    run_apart("int_and_array_apart", (4, 5, 6), lambda D: (2, slice(None), D(ic)), {"i0": ic})
+    run_apart("int_next_to_array", (4, 5, 6), lambda D: (slice(None), 3, D(ic)), {"i0": ic})
+    run_apart("array_int_array", (4, 5, 6), lambda D: (D(ia), -2, D(ib)), {"i0": ia, "i1": ib})
+    icol = rng6.permutation(4)[:3].reshape(3, 1).astype(np.int64)
+    irow = rng6.permutation(6)[:2].astype(np.int64)
+    run_apart("arrays_apart_broadcast", (4, 5, 6), lambda D: (D(icol), slice(None, None, 2), D(irow)), {"i0": icol, "i1": irow})
+    mk = rng6.uniform(0, 1, 5) > 0.4
+    mk[1] = True
+    ik = rng6.permutation(6)[:int(mk.sum())].astype(np.int64)
+    run_apart("mask_and_array", (4, 5, 6), lambda D: (slice(None), D(mk), D(ik)), {"mask": mk, "i0": ik})
+    run_apart("mask_apart_from_array", (5, 3, 6), lambda D: (D(mk), slice(None), D(ik)), {"mask": mk, "i0": ik})
+    a = f32(rng6, -1, 1, (4, 5, 6))
+    v = f32(rng6, -1, 1, (5, 5))
+    t = T.from_numpy(a.copy(), requires_grad=False)
+    with light.no_grad():
+        t[T.from_numpy(ia, requires_grad=False), :, T.from_numpy(ib, requires_grad=False)] = T.from_numpy(v, requires_grad=False)
+    fi3["put_arrays_apart/in"], fi3["put_arrays_apart/i0"], fi3["put_arrays_apart/i1"], fi3["put_arrays_apart/val"], fi3["put_arrays_apart/out"] = a, ia, ib, v, np.array(t.numpy())
+    np.savez_compressed(os.path.join(OUT, "fancy_index_apart.npz"), **fi3)
+
+    # ---------------------------------------------------------------- tensors that are not float32 (round 4): what the reference's
+    # CPU backend - numpy - computes for int16 / int32 / int64 / float64 operands (cpu/tensor.py:45-46 keeps the dtype;
+    # cpu/ops.py:52-84, :120-139, :260-293): neg, add, sub, mul (+ scalar operands, broadcasting, a transposed view), the
+    # in-place forms, sum / max / min over None / 0 / 1, and for float64 div, pow and the gradients of a small expression
+    ty = {}
+    rng = np.random.RandomState(2026)
+    for dt in (np.int16, np.int32, np.int64, np.float64):
+        name = np.dtype(dt).name
+        if dt is np.float64:
+            a, b, row = rng.uniform(-3, 3, (7, 9)), rng.uniform(0.5, 3, (7, 9)), rng.uniform(-2, 2, (9,))
+        else:
+            info = np.iinfo(dt)
+            a = rng.randint(info.min // 2, info.max // 2, (7, 9)).astype(dt)
+            b = rng.randint(info.min // 2, info.max // 2, (7, 9)).astype(dt)      # sums / products wrap around: numpy's bits
+            row = rng.randint(-100, 100, (9,)).astype(dt)
+        a[2, 3] = a[5, 1] = a.max()                                         # ties for max
+        ty[name + "/a"], ty[name + "/b"], ty[name + "/row"] = a, b, row
+        A, Bt, R = T.from_numpy(a), T.from_numpy(b), T.from_numpy(row)
+        with light.no_grad():
+            ty[name + "/neg"] = (-A).numpy()
+            ty[name + "/add"] = (A + Bt).numpy()
+            ty[name + "/sub"] = (A - Bt).numpy()
+            ty[name + "/mul"] = (A * Bt).numpy()
+            ty[name + "/add_row"] = (A + R).numpy()
+            ty[name + "/mul_transposed"] = (A.transpose(1, 0) * Bt.transpose(1, 0)).numpy()
+            ty[name + "/add_scalar"] = (A + 3).numpy()
+            ty[name + "/rmul_scalar"] = (5 * A).numpy()
+            ty[name + "/add_float_scalar"] = (A + 0.5).numpy()               # integers: float64 result
+            acc = T.from_numpy(a.copy())
+            acc += Bt
+            acc *= R
+            acc -= 7
+            ty[name + "/inplace"] = acc.numpy()
+            for ax, tag in ((None, "all"), (0, "0"), (1, "1")):
+                ty["%s/sum_%s" % (name, tag)] = np.asarray(A.sum(axis=ax).numpy())
+                ty["%s/max_%s" % (name, tag)] = np.asarray(A.max(axis=ax).numpy())
+                ty["%s/min_%s" % (name, tag)] = np.asarray(A.min(axis=ax).numpy())
+            ty[name + "/sum_keepdims"] = A.sum(axis=1, keepdims=True).numpy()
+            if dt is np.float64:
+                ty[name + "/div"] = (A / Bt).numpy()
+                ty[name + "/pow"] = (Bt ** A).numpy()
+        if dt is np.float64:
+            # gradients through the tape in float64: d/da, d/db of ((a * b + row) * a - b).max(axis=1) weighted by w
+            w = rng.uniform(-1, 1, (7,))
+            ty[name + "/w"] = w
+            A, Bt, R = T.from_numpy(a), T.from_numpy(b), T.from_numpy(row)
+            y = ((A * Bt + R) * A - Bt)
+            (y * T.from_numpy(w.reshape(7, 1))).backward(allow_fill=True)
+            ty[name + "/y"] = y.numpy()
+            ty[name + "/grad_a"], ty[name + "/grad_b"], ty[name + "/grad_row"] = A.grad.numpy(), Bt.grad.numpy(), R.grad.numpy()
+    for k, v in ty.items():
+        assert isinstance(v, np.ndarray), k
+    np.savez_compressed(os.path.join(OUT, "typed_ops.npz"), **ty)
+
     # ---------------------------------------------------------------- tiny-BERT forward (BASELINE config #5)
     # model classes loaded from the reference's examples/bert.py by file path; its Embedding.forward hard-codes
     # `.opencl()` (bert.py:19-21), replaced here by the same CPU lookup without the device hop.

@@ -124,3 +124,44 @@ def test_several_index_arrays_and_masks(name):
 
 def test_several_index_arrays_and_masks_in_place():
     check_multi_inplace(CpuTensor, load_golden("fancy_index_multi.npz"))
+
+
+# ---- index arrays on NON-neighbouring axes, ints among them, a mask next to an array (tests/golden/fancy_index_apart.npz) ----
+APART_CASES = {
+    "arrays_apart": lambda D, g, n: (D(g[n + "/i0"]), slice(None), D(g[n + "/i1"])),
+    "arrays_apart_4d": lambda D, g, n: (D(g[n + "/i0"]), slice(1, 3), D(g[n + "/i1"])),
+    "int_and_array_apart": lambda D, g, n: (2, slice(None), D(g[n + "/i0"])),
+    "int_next_to_array": lambda D, g, n: (slice(None), 3, D(g[n + "/i0"])),
+    "array_int_array": lambda D, g, n: (D(g[n + "/i0"]), -2, D(g[n + "/i1"])),
+    "arrays_apart_broadcast": lambda D, g, n: (D(g[n + "/i0"]), slice(None, None, 2), D(g[n + "/i1"])),
+    "mask_and_array": lambda D, g, n: (slice(None), D(g[n + "/mask"]), D(g[n + "/i0"])),
+    "mask_apart_from_array": lambda D, g, n: (D(g[n + "/mask"]), slice(None), D(g[n + "/i0"])),
+}
+
+
+def check_apart(cls, g, name):
+    for as_tensor in (True, False):
+        D = (lambda v: cls.from_numpy(v, requires_grad=False)) if as_tensor else (lambda v: v)
+        t = cls.from_numpy(g[name + "/in"].copy())
+        y = t[APART_CASES[name](D, g, name)]
+        assert y.shape == g[name + "/out"].shape, (name, y.shape, g[name + "/out"].shape)
+        np.testing.assert_array_equal(y.numpy(), g[name + "/out"])
+        (y * cls.from_numpy(g[name + "/w"], requires_grad=False)).backward(allow_fill=True)
+        np.testing.assert_array_equal(t.grad.numpy(), g[name + "/grad"])
+
+
+def check_apart_inplace(cls, g):
+    D = lambda v: cls.from_numpy(v, requires_grad=False)          # noqa: E731
+    t = cls.from_numpy(g["put_arrays_apart/in"].copy(), requires_grad=False)
+    with light.no_grad():
+        t[D(g["put_arrays_apart/i0"]), :, D(g["put_arrays_apart/i1"])] = D(g["put_arrays_apart/val"])
+    np.testing.assert_array_equal(t.numpy(), g["put_arrays_apart/out"])
+
+
+@pytest.mark.parametrize("name", sorted(APART_CASES))
+def test_index_arrays_apart(name):
+    check_apart(CpuTensor, load_golden("fancy_index_apart.npz"), name)
+
+
+def test_index_arrays_apart_in_place():
+    check_apart_inplace(CpuTensor, load_golden("fancy_index_apart.npz"))

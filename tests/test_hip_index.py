@@ -7,7 +7,7 @@ import pytest
 import lightgrad_amd as light
 from lightgrad_amd import CpuTensor
 from conftest import load_golden
-from test_fancy_index_cpu import TAKE_CASES, PAIR_CASES, MULTI_CASES, check_take, check_inplace, check_dataset, check_multi, check_multi_inplace
+from test_fancy_index_cpu import APART_CASES, check_apart, check_apart_inplace, TAKE_CASES, PAIR_CASES, MULTI_CASES, check_take, check_inplace, check_dataset, check_multi, check_multi_inplace
 
 pytestmark = pytest.mark.gpu
 
@@ -47,8 +47,50 @@ def test_index_forms_that_are_errors(hip):
         t[np.asarray([0, 1, 2]), np.asarray([1, 2])]
     with pytest.raises(IndexError, match="boolean index did not match"):
         t[np.zeros((4, 4), bool)]
-    with pytest.raises(NotImplementedError, match="neighbouring"):
-        t[np.asarray([0, 1]), :, np.asarray([1, 2])]
+    assert t[np.asarray([0, 1]), :, np.asarray([1, 2])].shape == (2, 5)         # index arrays apart: their dimension goes first
+    with pytest.raises(IndexError, match="newaxis"):
+        t[np.asarray([0, 1]), None, np.asarray([1, 2])]
+
+
+@pytest.mark.parametrize("name", sorted(APART_CASES))
+def test_index_arrays_apart(hip, name):
+    """index arrays on non-neighbouring axes (numpy moves the index dimensions to the front), plain integers among index arrays, a
+    mask next to an array - values, shapes and gradients against fixtures recorded from the reference's CPU path; the index arrays
+    as device tensors (folded on the device, no read-back) and as host arrays"""
+    check_apart(hip, load_golden("fancy_index_apart.npz"), name)
+
+
+def test_index_arrays_apart_in_place(hip):
+    check_apart_inplace(hip, load_golden("fancy_index_apart.npz"))
+
+
+def test_device_indices_are_not_read_back(hip, monkeypatch):
+    """several device-resident index arrays are folded by a kernel: nothing but a boolean mask's COUNT may come back to the host"""
+    rng = np.random.RandomState(8)
+    a = rng.uniform(-1, 1, (6, 5, 7)).astype(np.float32)
+    t = hip.from_numpy(a)
+    i0, i1 = rng.randint(0, 6, (4, 3)), rng.randint(-7, 7, (3,))
+    d0, d1 = hip.from_numpy(i0.astype(np.int32), requires_grad=False), hip.from_numpy(i1.astype(np.int64), requires_grad=False)
+    mask = rng.uniform(0, 1, (6, 5)) > 0.5
+    dm = hip.from_numpy(mask, requires_grad=False)
+    reads = []
+    real = hip.numpy
+    monkeypatch.setattr(hip, "numpy", lambda self: (reads.append(self.shape), real(self))[1])
+    y = t[d0, :, d1]
+    z = t[dm]
+    monkeypatch.setattr(hip, "numpy", real)
+    assert reads == [(1,)], reads                     # the mask's count, nothing else
+    np.testing.assert_array_equal(y.numpy(), a[i0, :, i1])
+    np.testing.assert_array_equal(z.numpy(), a[mask])
+    bad = hip.from_numpy(np.asarray([0, 6]), requires_grad=False)          # out of range on the device: reported at the next sync
+    out = t[bad, :, hip.from_numpy(np.asarray([1, 2]), requires_grad=False)]
+    with pytest.raises(IndexError):
+        out.numpy()
+    big = rng.uniform(0, 1, (300, 41)) > 0.7                              # a mask over several scan blocks
+    src = rng.uniform(-1, 1, (300, 41, 2)).astype(np.float32)
+    np.testing.assert_array_equal(hip.from_numpy(src)[hip.from_numpy(big, requires_grad=False)].numpy(), src[big])
+    none = np.zeros((300, 41), bool)
+    assert hip.from_numpy(src)[hip.from_numpy(none, requires_grad=False)].shape == (0, 2)
 
 
 def test_dataset_epoch_matches_reference(hip):

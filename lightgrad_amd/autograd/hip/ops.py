@@ -721,7 +721,9 @@ class astype(Function):
     cpu/tensor.py:12).  Differentiable between float dtypes: the gradient is cast back. """
     def forward(ctx, t, dtype=np.float32):
         ctx.save_for_backward(t._dtype, np.dtype(dtype))
-        return _cast(t, dtype) if np.dtype(dtype) != t._dtype else _unary(_l.EW_COPY, t)
+        out = _cast(t, dtype) if np.dtype(dtype) != t._dtype else _unary(_l.EW_COPY, t)
+        out._requires_grad = True             # (whether it joins the tape is the Function machinery's call, from the input)
+        return out
 
     def backward(ctx, out_grad):
         src, dst = ctx.get_saved_tensors()
@@ -915,8 +917,8 @@ def _take_plan(a, idx):
         if i is None or i is Ellipsis:
             continue
         n_real += len(i._shape if isinstance(i, HipTensor) else np.asarray(i).shape) if _is_advanced(i) and _is_bool_index(i) else 1
-    if Ellipsis in idx:
-        k = idx.index(Ellipsis)
+    if any(i is Ellipsis for i in idx):             # (`Ellipsis in idx` would compare the index arrays with ==)
+        k = next(k for k, i in enumerate(idx) if i is Ellipsis)
         idx = idx[:k] + (slice(None),) * (len(a._shape) - n_real) + idx[k + 1:]
     # where every entry lands: axis of `a` it starts at, kind
     arrays = [i for i in idx if _is_advanced(i) and not _is_bool_index(i)]

@@ -117,14 +117,11 @@ def dry_rank(args, rank, world):
     import lightgrad_amd as light
     from lightgrad_amd import CpuTensor
     from lightgrad_amd.dist import GlooCommunicator, SingleProcess, DataParallel
+    why_not = {}
     if world > 1:
-        import torch.distributed as dist
-        from lightgrad_amd.dist import _c_stdout_to_stderr
-        with _c_stdout_to_stderr():              # gloo announces its connections on the C-level stdout
-            dist.init_process_group("gloo", init_method="tcp://%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]),
-                                    rank=rank, world_size=world)
-            comm = GlooCommunicator()
-            comm.barrier()
+        # the same opening protocol as the GPU ranks (attempt under a timeout, vote through the rendezvous files, next form): here
+        # the two device forms cannot work - no GPU in a dry run - so the chain is walked to its last link, the host communicator
+        comm, _, comms, why_not = open_job_communicators(args, rank, world, None, dry=True)
     else:
         comm = SingleProcess()
 
@@ -178,6 +175,7 @@ def dry_rank(args, rank, world):
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "cpu stand-in: mlp_64x32x10 batch 32, CpuTensor + gloo", "parallelism": "dp%d" % world},
                           "ranks": {"world_size": world, "communicator": type(comm).__name__, "communicator_ranks": comm.world_size,
+                                    "communicators_not_usable": why_not or None,
                                     "per_rank_steps_per_sec": [round(float(v), 2) for v in rates.numpy()],
                                     "launcher": "lightgrad_amd.launch" if os.environ.get("LIGHTGRAD_LAUNCHED") else "external"}}))
     if world > 1:
@@ -210,14 +208,19 @@ def preflight_report(lib, L, rank, world):
             "can_access_peer": access, "link_type": links, "hops": hop_counts}
 
 
-def open_job_communicators(args, rank, world, L):
-    """-> (bookkeeping communicator, peer-window communicator or None, {name: comm}, {name: why not})"""
-    from lightgrad_amd.dist import RcclCommunicator, PeerWindowCommunicator, open_communicators, peer_window_selftest
+def open_job_communicators(args, rank, world, L, dry=False):
+    """-> (bookkeeping communicator, peer-window communicator or None, {name: comm}, {name: why not}).
+    dry: no GPU (bench.py --dry-run) - the device forms fail at once and the chain ends at the host communicator over gloo"""
+    from lightgrad_amd.dist import open_communicators
     T = args.comm_open_timeout
     simulate = os.environ.get("LG_BENCH_FAIL_RCCL", "")            # tests of the fallback: "init", "init:<rank>", "hang"
     rehearsal = args.rehearse_on_one_gpu and world > 1
+    Failure = RuntimeError if dry else L.HipError
 
     def open_rccl():
+        if dry:
+            raise Failure("dry run: no GPU, no RCCL")
+        from lightgrad_amd.dist import RcclCommunicator
         if simulate.startswith("init") and (":" not in simulate or int(simulate.split(":")[1]) == rank):
             raise L.HipError("simulated RCCL initialisation failure (LG_BENCH_FAIL_RCCL=%s)" % simulate)
         if simulate:                                    # "hang", or a rank whose peer failed: what ncclCommInitRank does then
@@ -225,6 +228,9 @@ def open_job_communicators(args, rank, world, L):
         return RcclCommunicator(rank, world, rendezvous_timeout=T, selftest_timeout=max(5.0, T / 2))
 
     def open_peer():
+        if dry:
+            raise Failure("dry run: no GPU, no peer windows")
+        from lightgrad_amd.dist import PeerWindowCommunicator, peer_window_selftest
         return peer_window_selftest(PeerWindowCommunicator(rank, world, rendezvous_timeout=T))
 
     openers = []
@@ -237,10 +243,10 @@ def open_job_communicators(args, rank, world, L):
         def open_host():
             import datetime
             import torch.distributed as dist
-            from lightgrad_amd.dist import HostStagedCommunicator, _c_stdout_to_stderr
-            with _c_stdout_to_stderr():
+            from lightgrad_amd.dist import HostStagedCommunicator, GlooCommunicator, _c_stdout_to_stderr
+            with _c_stdout_to_stderr():              # gloo announces its connections on the C-level stdout
                 dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(30.0, T)))
-                c = HostStagedCommunicator()
+                c = GlooCommunicator() if dry else HostStagedCommunicator()
                 c.barrier()
             return c
         more, why_more = open_communicators(rank, world, [("host", open_host)], timeout=max(60.0, T) + 120.0)   # first `import torch` on a fresh box: minutes
@@ -248,7 +254,7 @@ def open_job_communicators(args, rank, world, L):
         why_not.update(why_more)
     comm = comms.get("rccl") or comms.get("peer") or comms.get("host")
     if comm is None:
-        raise L.HipError("no form of the gradient exchange works on this node: %s" % json.dumps(why_not))
+        raise Failure("no form of the gradient exchange works on this node: %s" % json.dumps(why_not))
     return comm, comms.get("peer"), comms, why_not
 
 

@@ -35,6 +35,9 @@ def test_bench_self_launch_two_ranks_dry_run():
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 5
     ranks = out["ranks"]
     assert ranks["world_size"] == 2 and ranks["communicator_ranks"] == 2 and ranks["launcher"] == "lightgrad_amd.launch"
+    # the ranks walked the whole chain of communicators (dist.open_communicators: attempt, vote, next form) down to the host one
+    assert ranks["communicator"] == "GlooCommunicator"
+    assert "no RCCL" in ranks["communicators_not_usable"]["rccl"] and "no peer windows" in ranks["communicators_not_usable"]["peer"]
     assert len(ranks["per_rank_steps_per_sec"]) == 2 and all(v > 0 for v in ranks["per_rank_steps_per_sec"])
     # aggregate = ranks x steps / slowest rank's time: never above the sum of the per-rank rates
     assert 0 < out["value"] <= sum(ranks["per_rank_steps_per_sec"]) * 1.001

@@ -12,11 +12,13 @@ shutil.copy(os.path.join(src, "mlp_step_trace.txt"), os.path.join(dst, "mlp_step
 shutil.copy(os.path.join(src, "gemm_sweep.txt"), os.path.join(dst, "gemm_sweep_%s.txt" % tag))
 for extra in ("hbm_bench", "mlp_gemm_bench", "head_bench", "gemm_timeline", "pmc_sq_mlp_gemm", "step_gap_one_step_per_graph",
               "step_gap_eight_steps_per_graph", "wrap_summary", "bert_step_trace", "bert_bench", "bert_gemm_bench", "ce_bench", "graph_branch_probe", "soak", "dist_two_ranks_one_gpu",
-              "p2p_bench_cu_masked", "p2p_bench_no_mask", "ipc_probe", "gemm_ring_lab_run", "attn_timeline"):
+              "p2p_bench_cu_masked", "p2p_bench_no_mask", "ipc_probe", "gemm_ring_lab_run", "attn_timeline", "mlp_step_ab",
+              "step_trace_update_in_backward"):
     if os.path.exists(os.path.join(src, extra + ".txt")):
         shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
-if os.path.exists(os.path.join(src, "bench_rehearsal_two_ranks_one_gpu.json")):
-    shutil.copy(os.path.join(src, "bench_rehearsal_two_ranks_one_gpu.json"), os.path.join(dst, "bench_rehearsal_two_ranks_one_gpu_%s.json" % tag))
+for name in ("bench_rehearsal_two_ranks_one_gpu", "bench_rehearsal_rccl_fallback", "bench_update_in_backward"):
+    if os.path.exists(os.path.join(src, name + ".json")):
+        shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, "%s_%s.json" % (name, tag)))
 pmc = {}
 for kind in ("fetch", "write"):
     f = newest("%s/%s/*/*_counter_collection.csv" % (src, kind))

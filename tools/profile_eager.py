@@ -74,3 +74,4 @@ pr.disable()
 HipDevice.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumtime").print_stats(45)

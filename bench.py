@@ -913,7 +913,7 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
         def bert_iter():
             logits = bmodel(ids)
             loss = light.loss.cross_entropy(logits.reshape(-1, bert.TINY["vocab_size"]), mlm_labels)   # masked-LM loss, every position
-            bdp.bucket.fill(0)
+            bdp.zero_grad()                  # lazily: the backward kernels overwrite; only scatter-added tables are really filled
             loss.backward()
         for _ in range(3):
             bert_iter()

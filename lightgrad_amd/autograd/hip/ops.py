@@ -234,6 +234,31 @@ class reshape(Function):
         return out_grad.reshape(*shape)
 
 
+_tape_reshape = HipTensor.reshape
+
+
+def _reshape_or_self(self, *shape):
+    """`t.reshape(...)`.  Peephole: a dense tensor asked for the shape it already has (the `x.reshape(-1, 784)` in front of an MLP
+    that is fed (batch, 784) rows) is returned as it is - no tape node, no dispatch (6 us of host time in the eager step, twice:
+    the node also has a backward).  The reference returns a second tensor on the same array (cpu/ops.py:38-47); every use of it -
+    values, in-place writes, gradients - is a use of the tensor itself."""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+        shape = tuple(shape[0])
+    if len(shape) == len(self._shape) and self._data is not None and self._dense is not False:
+        same = True
+        for want, have in zip(shape, self._shape):
+            if want != have and want != -1:
+                same = False
+                break
+        if same and shape.count(-1) <= 1 and self.is_contiguous():
+            return self
+    return _tape_reshape(self, *shape)
+
+
+_reshape_or_self.__name__ = "reshape"
+HipTensor.reshape = _reshape_or_self
+
+
 """ Basic math """
 
 

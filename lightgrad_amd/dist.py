@@ -661,6 +661,13 @@ class DataParallel(object):
             p._materialize_zero_grad()            # a lazily zeroed gradient no kernel has written yet (optim.zero_grad)
         self.comm.allreduce_sum_(self.bucket)
 
+    def zero_grad(self) -> None:
+        """zero the gradient bucket LAZILY (what `Optimizer.zero_grad` does once it holds the flat buckets): every parameter's
+        gradient view is marked "zero pending" - the first backward kernel that reaches it overwrites instead of adding, readers
+        and accumulating writers fill first - so no pass over the bucket happens here"""
+        for p in self.parameters:
+            p._grad_zero_pending = True
+
     def parameter_digest(self) -> float:
         """sum of |w| over all parameters: equal on every rank iff the replicas are in sync"""
         return float(sum(np.abs(p.numpy().astype(np.float64)).sum() for p in self.parameters))

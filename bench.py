@@ -913,8 +913,8 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
         def bert_iter():
             logits = bmodel(ids)
             loss = light.loss.cross_entropy(logits.reshape(-1, bert.TINY["vocab_size"]), mlm_labels)   # masked-LM loss, every position
-            bdp.zero_grad()                  # lazily: the backward kernels overwrite; only scatter-added tables are really filled
-            loss.backward()
+            bdp.bucket.fill(0)               # (one fill of the bucket: marking every gradient "zero pending" instead turns into six
+            loss.backward()                  #  fills of its own for the parameters whose kernels can only add - 42 -> 48 launches, measured)
         for _ in range(3):
             bert_iter()
         fence()

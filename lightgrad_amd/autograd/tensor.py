@@ -221,12 +221,17 @@ class AbstractTensor(metaclass=_TensorType):
         if self._requires_grad:
             if self._grad is None or self._grad_shared:
                 self._grad, self._grad_shared = self.__class__.zeros(self.shape, requires_grad=False), False
-            else:
-                # LAZY for a tensor that already owns its gradient buffer: the first backward kernel that reaches it overwrites
-                # (GEMM with beta = 0, `_consume_zero_pending`), `add_grad` and every reader (`.grad`) fill first
-                # (`_materialize_zero_grad`).  Saves one pass over the buffer here and the read of the zeros in the accumulating
-                # epilogue: 4096^2 matmul forward+backward, two 64 MiB gradients: 2.95 -> 2.91 ms per iteration
+            elif self._ctx is None:
+                # LAZY for a LEAF that already owns its gradient buffer: the first backward kernel that reaches it overwrites
+                # (GEMM with beta = 0: every user of `_grad_accumulator()` asks `_consume_zero_pending()`), `add_grad` and every
+                # reader (`.grad`) fill first (`_materialize_zero_grad`).  Saves one pass over the buffer here and the read of the
+                # zeros in the accumulating epilogue: 4096^2 matmul forward+backward with its two 64 MiB gradients 139.7 -> 143.7
+                # TFLOP/s together with the register work on the large tile.  NOT for intermediates: backward ops add into an
+                # intermediate's `_grad` directly (the residual branch of `linear._input_product`) - a pending fill would wipe it
+                # at the next read (found by gradcheck's repeated backward passes over one tape).
                 self._grad_zero_pending = True
+            else:
+                self._grad.fill(0)
 
     """ Registration of operations and backends """
 

@@ -58,7 +58,7 @@ def main():
     def step():
         logits = model(ids)
         state["loss"] = light.loss.cross_entropy(logits.reshape(-1, bert.TINY["vocab_size"]), labels)
-        dp.zero_grad()
+        dp.bucket.fill(0)
         state["loss"].backward()
     for _ in range(3):
         step()

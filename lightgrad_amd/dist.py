@@ -10,6 +10,15 @@ addition for BASELINE config #4.  Design:
   * `mse.backward` carries no 1/N (loss.py:12), so the all-reduce SUM equals the gradient of the
     concatenated batch; the mean (x 1/world) is folded into the optimizer (`grad_scale`).
 
+When a rank is lost (the peer-window forms).  A wait inside an exchange launch gives up after 20 s; the next synchronising call
+raises HipError (LG_ECOMM) naming the chunk, the rank and the exchange it waited for.  From then on `comm.failed()` is True: the
+gradient bucket and the parameters of this rank are NOT to be trusted (the step that failed may have applied a partial sum), every
+further collective on the communicator is refused, graphs that recorded its launches report again when replayed.  What a training
+loop can do: `comm.close()` (returns at once, no barrier with the lost peer), then either end the job (bench.py: exit code 3) or,
+with the surviving ranks renumbered by the launcher, open a new communicator (`open_communicators`), build a new DataParallel
+around the model - its constructor broadcasts rank 0's parameters, which are from the last COMPLETED step on any rank that raised
+before its own update ran - and re-capture any hipGraph that held an exchange.  Optimizer moments are per rank and stay valid.
+
 Communicators with the same interface:
   PeerWindowCommunicator  HipTensor buckets, hand-written exchange through peer-mapped device memory (include/lghip_p2p.h):
                     ordinary kernels, and the gradient exchange fused into the optimizer launch

@@ -16,7 +16,7 @@ for extra in ("hbm_bench", "mlp_gemm_bench", "head_bench", "gemm_timeline", "pmc
               "step_trace_update_in_backward"):
     if os.path.exists(os.path.join(src, extra + ".txt")):
         shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
-for name in ("bench_rehearsal_two_ranks_one_gpu", "bench_rehearsal_rccl_fallback", "bench_update_in_backward"):
+for name in ("bench_rehearsal_two_ranks_one_gpu", "bench_rehearsal_rccl_fallback", "bench_rehearsal_under_torchrun", "bench_update_in_backward"):
     if os.path.exists(os.path.join(src, name + ".json")):
         shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, "%s_%s.json" % (name, tag)))
 pmc = {}

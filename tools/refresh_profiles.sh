@@ -32,6 +32,7 @@ step bertgemm 100 "python tools/bert_gemm_bench.py > $out/bert_gemm_bench.txt 2>
 step cebench 100 "python tools/ce_bench.py > $out/ce_bench.txt 2>&1; LG_CE_HELD=0 python tools/ce_bench.py >> $out/ce_bench.txt 2>&1"; cat $out/ce_bench.txt
 step rehearse 400 "python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-cpu-baseline > $out/bench_rehearsal_two_ranks_one_gpu.json 2> $out/bench_rehearsal.err"; tail -c 300 $out/bench_rehearsal_two_ranks_one_gpu.json
 step rehearsefb 400 "LG_BENCH_FAIL_RCCL=init:1 python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-extras --comm-open-timeout 5 > $out/bench_rehearsal_rccl_fallback.json 2> $out/bench_rehearsal_rccl_fallback.err"; tail -c 300 $out/bench_rehearsal_rccl_fallback.json
+step torchrun 400 "python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-extras > $out/bench_rehearsal_under_torchrun.json 2> $out/bench_rehearsal_under_torchrun.err"; tail -c 300 $out/bench_rehearsal_under_torchrun.json
 step ab 100 "python tools/mlp_step_ab.py 3 > $out/mlp_step_ab.txt 2>&1"; cat $out/mlp_step_ab.txt
 step traceub 200 "w=\$(mktemp -d /tmp/tr_XXXX); rocprofv3 --kernel-trace --output-format csv -d \$w -- python3 bench.py --steps 400 --warmup 40 --graph-steps 8 --no-extras --update-in-backward > $out/bench_update_in_backward.json 2> $out/traceub.err; python tools/kernel_window.py \$(find \$w -name '*kernel_trace.csv' | head -1) 8 head_fwd > $out/step_trace_update_in_backward.txt; rm -rf \$w"; cat $out/step_trace_update_in_backward.txt
 step dist2 300 "python -m pytest tests/test_hip_dist.py -m gpu -q > $out/dist_two_ranks_one_gpu.txt 2>&1"; tail -2 $out/dist_two_ranks_one_gpu.txt

@@ -55,6 +55,9 @@ class BertEmbedding(nn.Module):
         if key not in self._const_ids:
             self._const_ids[key] = (cls.from_numpy(np.zeros(shape, dtype=np.int32), requires_grad=False),
                                     cls.from_numpy(np.arange(shape[-1], dtype=np.int32), requires_grad=False))
+            for t in self._const_ids[key]:
+                if hasattr(t, "freeze"):
+                    t.freeze()              # constants of the model: a backend may keep what it derives from them (and record it in graphs)
         return self._const_ids[key]
 
     def forward(self, input_ids, token_type_ids=None):

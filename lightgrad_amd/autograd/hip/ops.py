@@ -1198,17 +1198,18 @@ def _tiled_ids(ids, shape):
     """the id tensor `ids` repeated along leading axes up to `shape`, as a dense tensor of its own.  Position ids are constants
     of a model, so the copy is kept with the id tensor's STORAGE (HipBuffer.derived) - every in-place writer into that storage
     (upload_, setitem, fill: tensor.flush_lazy_readers) drops it, and inside a hipGraph capture it is made anew each time, so
-    that a replay tiles whatever the id buffer holds then."""
+    that a replay tiles whatever the id buffer holds then - unless the model has declared the ids constant (`HipTensor.freeze()`)."""
     from .graph import HipGraph
     buf = ids.data
     key = (ids._offset, ids._shape, ids._strides, tuple(shape))
-    if not HipGraph.capturing and buf.derived is not None:
+    keep = buf.frozen or not HipGraph.capturing          # (a frozen tensor cannot be refreshed: its copy may live in a graph)
+    if keep and buf.derived is not None:
         hit = buf.derived.get(key)
         if hit is not None:
             return hit
     lead = len(shape) - len(ids._shape)
     tiled = HipTensor(buf, tuple(shape), (0,) * lead + tuple(ids._strides), ids._offset, ids._dtype, requires_grad=False).contiguous()
-    if not HipGraph.capturing:
+    if keep:
         if buf.derived is None:
             buf.derived = {}
         buf.derived[key] = tiled

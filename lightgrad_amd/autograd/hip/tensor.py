@@ -38,12 +38,13 @@ def contiguous_strides(shape):
 
 class HipBuffer(object):
     """Owner of one pool allocation; returned to the pool when the last tensor viewing it dies."""
-    __slots__ = ("ptr", "nbytes", "lazy_readers", "derived", "__weakref__")
+    __slots__ = ("ptr", "nbytes", "lazy_readers", "derived", "frozen", "__weakref__")
 
     def __init__(self, nbytes):
         self.ptr = None
         self.lazy_readers = None      # weak references to lazy tensors that will still READ this block (see flush_lazy_readers)
         self.derived = None           # tensors computed from this block's CONTENTS and kept for reuse (ops._tiled_ids): dropped by any in-place writer
+        self.frozen = False           # HipTensor.freeze(): a constant - in-place writers raise, results derived from it may be recorded in hipGraphs
         p = ctypes.c_void_p()
         _l.check(_l.lib().lg_malloc(ctypes.byref(p), max(int(nbytes), 1)))
         self.ptr = p.value
@@ -144,6 +145,8 @@ def flush_lazy_readers(t) -> None:
         GradGroup.flush()              # storage that a queued launch will read or write
     _make_lazy_readers_real(t)
     buf = t._data
+    if buf is not None and buf.frozen:
+        raise RuntimeError("in-place write into a frozen HipTensor (HipTensor.freeze(): a constant whose derived copies hipGraphs may hold)")
     if buf is not None and buf.derived is not None:
         buf.derived = None             # cached results made from the old contents (ids tiled once, then refreshed in place)
 
@@ -396,6 +399,13 @@ class HipTensor(AbstractTensor):
             else:
                 out = _ops._gemm(x, _ops._swap_last(weight), bias=bias)
         self._data, self._offset, self._byte_offset, self._lazy_source = out._data, out._offset, out._byte_offset, None
+
+    def freeze(self) -> "HipTensor":
+        """declare this tensor's storage a CONSTANT (a model's position ids): every later in-place write into it raises, and results
+        the library derives from its contents and keeps (the ids tiled over a batch) may be recorded in hipGraphs without being made
+        anew at every capture"""
+        self.data.frozen = True
+        return self
 
     def _watch_sources(self, *sources) -> None:
         """register this lazy tensor with the storage of everything it will read (see flush_lazy_readers)"""

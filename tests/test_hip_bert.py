@@ -429,6 +429,14 @@ def test_shared_ids_refreshed_in_place_are_tiled_again(hip):
         np.testing.assert_allclose(position_gradient(), want, rtol=1e-5, atol=1e-6, err_msg=refresh)
 
 
+def test_frozen_tensors_refuse_in_place_writes(hip):
+    t = hip.from_numpy(np.arange(6, dtype=np.int32), requires_grad=False).freeze()
+    for write in (lambda: t.fill(1), lambda: t.upload_(np.zeros(6, np.int32)), lambda: t.__setitem__(slice(0, 2), 7)):
+        with pytest.raises(RuntimeError, match="frozen"):
+            write()
+    np.testing.assert_array_equal(t.numpy(), np.arange(6, dtype=np.int32))
+
+
 @pytest.mark.parametrize("rows,width,inner", [((8, 128), 128, 512), ((3, 10), 36, 52), ((70,), 64, 64)])
 def test_feed_forward_block_against_the_separate_ops(hip, rows, width, inner):
     """dense2(gelu(dense1(x))) + x as one node (gelu and its derivative in GEMM epilogues) against Linear, gelu, Linear, add

@@ -69,21 +69,6 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];          // [outs][hidden]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = a.outs * a.hidden;
-#ifndef LG_HEAD_FWD_NO_PREFETCH
-    // this wave's FIRST row is requested before W is staged: both round trips overlap instead of following each other (rows up
-    // to 1024 wide; the usual launch has one row per wave)
-    constexpr int kAhead = 4;
-    float4 ahead[kAhead];
-    const int64_t row_first = int64_t(blockIdx.x) * 4 + wave;
-    const bool use_ahead = a.hidden <= kAhead * 256 && row_first < a.rows;
-    if (use_ahead) {
-#pragma unroll
-        for (int c = 0; c < kAhead; ++c) {
-            const int k = lane * 4 + c * 256;
-            ahead[c] = k < a.hidden ? *reinterpret_cast<const float4*>(a.x + row_first * a.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-#endif
     for (int i = tid * 4; i < wn; i += 1024) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(a.w + i);
     __syncthreads();
     for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < a.rows; row += int64_t(gridDim.x) * 4) {
@@ -92,17 +77,7 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
         for (int j = 0; j < OMAX; ++j) acc[j] = 0.f;
         const float* p = a.x + row * a.ldx;
         for (int k = lane * 4; k < a.hidden; k += 256) {
-#ifndef LG_HEAD_FWD_NO_PREFETCH
-            float4 h;
-            if (use_ahead && row == row_first) {
-                const int c = (k - lane * 4) >> 8;
-                h = c == 0 ? ahead[0] : c == 1 ? ahead[1] : c == 2 ? ahead[2] : ahead[3];
-            } else {
-                h = *reinterpret_cast<const float4*>(p + k);
-            }
-#else
             float4 h = *reinterpret_cast<const float4*>(p + k);
-#endif
             if (a.relu) { h.x = relu_keep_nan(h.x); h.y = relu_keep_nan(h.y); h.z = relu_keep_nan(h.z); h.w = relu_keep_nan(h.w); }
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) {
@@ -158,11 +133,7 @@ struct HeadBwd {
 
 constexpr int kHeadThreads = 1024;                 // 16 wavefronts: a slab workgroup has a CU to itself
 constexpr int kHeadRows = 256, kHeadCols = 32;     // dx / gpre tile
-#ifndef LG_HEAD_SLAB_COLS
-#define LG_HEAD_SLAB_COLS 8
-#endif
-constexpr int kSlabCols = LG_HEAD_SLAB_COLS;       // columns of dW one reducing workgroup owns (over ALL rows): 8 or 4
-static_assert(kSlabCols == 8 || kSlabCols == 4, "a wavefront holds 64 / kSlabCols thread rows of the slab");
+constexpr int kSlabCols = 8;                       // columns of dW one reducing workgroup owns (over ALL rows)
 
 // Kinds of workgroups in one launch, none of which waits for another:
 //   slab workgroups  own 8 columns of dW for every row: 128 thread rows x 8 columns, g staged in LDS in chunks of up to
@@ -186,7 +157,7 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
     __shared__ float red[NW * OMAX * (kSlabCols + 1)];
     const int tid = threadIdx.x;
     if (int(blockIdx.x) < a.n_slabs) {
-        const int tc = tid % kSlabCols, tr = tid / kSlabCols, wave = tid >> 6;
+        const int tc = tid & 7, tr = tid >> 3, wave = tid >> 6;
         const int slab = blockIdx.x;
         const int k = slab * kSlabCols + tc;
         const bool kin = k < a.hidden;
@@ -232,17 +203,13 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
                     for (int j = 0; j < OMAX; ++j) dbacc[j] += g_lds[(tr + TR * i) * OMAX + j];
             }
         }
-        // the thread rows of a wavefront (lanes c, c + kSlabCols, ... share column c), then the 16 wavefronts through LDS
+        // the 8 thread rows of a wavefront (lanes c, c+8, ..., c+56 share column c), then the 16 wavefronts through LDS
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) {
 #pragma unroll
-            for (int off = kSlabCols; off < 64; off <<= 1) acc[j] += __shfl_xor(acc[j], off, 64);
-        }
-        if (slab == 0) {                                       // (uniform: only column 0 of slab 0 carries the bias gradient)
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) {
-#pragma unroll
-                for (int off = kSlabCols; off < 64; off <<= 1) dbacc[j] += __shfl_xor(dbacc[j], off, 64);
+            for (int off = 8; off < 64; off <<= 1) {
+                acc[j] += __shfl_xor(acc[j], off, 64);
+                dbacc[j] += __shfl_xor(dbacc[j], off, 64);     // only column 0 of slab 0 carries values; the others sum zeros
             }
         }
         if ((tid & 63) < kSlabCols) {

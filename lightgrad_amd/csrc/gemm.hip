@@ -367,10 +367,49 @@ static void pair_launch_single(const GemmArgs& g, int slot) {
     else           hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
 }
 
+// The K-slice count of the FIRST product of a pair (the weight gradient, the one that splits K) was chosen as if it had the chip
+// to itself; its workgroups share the CUs with the second product's.  Once both are known the count is chosen again from the same
+// microsecond model with the joint residency: K-tiles per workgroup x (0.43 c + 0.17) us for c = ceil(all workgroups of the launch /
+// CUs) resident per CU, + 1.8 + 0.85 slices for publishing and folding the slabs.  MNIST MLP (104 + 208 tiles, K = 1024): 5 slices
+// instead of 4 (728 workgroups: still three per CU; six would make four): the step 60.6 -> 59.6 us
+// (profiles/r4/pair_slices_sweep2.txt).  Batched first products keep what they have.
+static int pair_retune_first(PairState& P) {
+    GemmArgs& g = P.args[0];
+    const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n;
+    static const char* pair_slices_env = getenv("LG_GEMM_PAIR_SLICES");      // experiments: the forced counts stay
+    if (pair_slices_env || g.nwg != tiles * g.k_slices || g.seg_k || tiles >= 256 || g.K < 128) return LG_OK;
+    constexpr int BK = 32, BM = 64, BN = 64;
+    const double cus = rt().compute_units > 0 ? rt().compute_units : 256;
+    const int64_t k_tiles = (g.K + BK - 1) / BK;
+    int64_t best_sl = g.k_slices;
+    double best = 1e30;
+    for (int64_t sl = 1; sl <= 64 && (sl == 1 || sl * 2 <= k_tiles); ++sl) {
+        const double per_cu = double(tiles * sl + P.args[1].nwg) / cus;
+        const double c = per_cu > 1.0 ? double(int64_t(per_cu + 0.999)) : 1.0;
+        const double cost = double((k_tiles + sl - 1) / sl) * (c <= 1.0 ? 0.68 : 0.43 * c + 0.17) + (sl > 1 ? 1.8 + 0.85 * double(sl) : 0.0);
+        if (cost < best) { best = cost; best_sl = sl; }
+    }
+    int64_t k_per_slice = ((g.K + best_sl - 1) / best_sl + BK - 1) / BK * BK;
+    best_sl = (g.K + k_per_slice - 1) / k_per_slice;
+    if (best_sl == g.k_slices) return LG_OK;
+    if (g.W) { const int rc = lg_free(g.W); g.W = nullptr; if (rc != LG_OK) return rc; }
+    g.k_per_slice = k_per_slice;
+    g.k_slices = int(best_sl);
+    g.nwg = int(tiles * best_sl);
+    g.div_slices = make_fastdiv(best_sl);
+    if (best_sl > 1) {
+        const int rc = lg_malloc(reinterpret_cast<void**>(&g.W), size_t(tiles * best_sl) * BM * BN * sizeof(float));
+        if (rc != LG_OK) return rc;
+    }
+    return LG_OK;
+}
+
 static int pair_flush(bool keep_collecting) {
     PairState& P = pair_state();
     int rc = LG_OK;
     if (P.count == 2) {
+        rc = pair_retune_first(P);
+        if (rc != LG_OK) { P.count = 0; return rc; }
 #ifdef LG_GEMM_TIMELINE
         if (P.args[0].tl) {
             (void)hipMemsetAsync(P.args[0].tl, 0, size_t(P.args[0].nwg + P.args[1].nwg) * 64, rt().stream);

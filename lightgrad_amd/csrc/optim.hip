@@ -130,10 +130,14 @@ namespace lg {
 constexpr int kMaxSegments = 64;
 struct AdamSegments {
     int     nseg;          // parameters in THIS launch (<= kMaxSegments)
-    int     nseg_total;    // parameters of the optimizer: the reference's `t` advances once per parameter (optim.py:36/:48)
+    int     nseg_total;    // parameters of the optimizer: the reference's `t` advances once per PARAMETER (optim.py:36/:48)
     int     first;         // index of this launch's first parameter
-    int     slot_base;     // step slot of workgroup (0, 0) of this launch
+    int     slot_base;     // step slot of workgroup 0 of this launch
     int     mirror_slot;   // the workgroup with this slot also writes step[0] (-1: none in this launch)
+    // COMPACT grid (round 4): parameter j owns workgroups wg_base[j] .. wg_base[j+1] - one per 1024 elements - instead of a row of
+    // a 2-D grid as wide as the LONGEST parameter needs: for the MNIST MLP that grid had 1568 workgroups of which 399 had work,
+    // and dispatching the 1169 that return at once is not free (the same lesson as the tail jobs of round 3)
+    int     wg_base[kMaxSegments + 1];
     int64_t offsets[kMaxSegments + 1];
 };
 
@@ -141,13 +145,14 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
                                                       float* __restrict__ v, AdamSegments seg, AdamScalars c,
                                                       int64_t* __restrict__ step, double b1, double b2, int own_slots, int base_aligned) {
     __shared__ float inv_bias[2];
-    const int j = blockIdx.y;
+    const int b = blockIdx.x;
+    int j = 0;
+    while (j + 1 < seg.nseg && b >= seg.wg_base[j + 1]) ++j;          // uniform: scalar loads
+    const int local = b - seg.wg_base[j], wgs = seg.wg_base[j + 1] - seg.wg_base[j];
     const int64_t begin = seg.offsets[j], n = seg.offsets[j + 1] - begin;
     // four elements per thread where the segment allows 16-byte accesses (vec == 1), else one
     const int vec = (base_aligned && (begin & 3) == 0) ? 1 : 0;
-    const int64_t first = (int64_t(blockIdx.x) * blockDim.x) * (vec ? 4 : 1);
-    if (first >= n) return;                            // workgroup-uniform
-    const int slot = seg.slot_base + j * int(gridDim.x) + int(blockIdx.x);
+    const int slot = seg.slot_base + b;
     int64_t steps_done = 0;
     if (threadIdx.x == 0) {
         // the two double-precision powers once per workgroup, not once per thread (they were most of the kernel)
@@ -163,9 +168,10 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
     const float* G = g + begin;
     float* M = m + begin;
     float* V = v + begin;
+    const int64_t stride = int64_t(wgs) * blockDim.x;
     if (vec) {
-        const int64_t nvec = n / 4, stride = int64_t(gridDim.x) * blockDim.x;
-        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const int64_t nvec = n / 4;
+        for (int64_t i = int64_t(local) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
             float4 pp = reinterpret_cast<float4*>(P)[i], gg = reinterpret_cast<const float4*>(G)[i];
             float4 mm = reinterpret_cast<float4*>(M)[i], vv = reinterpret_cast<float4*>(V)[i];
             adam_elem(pp.x, gg.x, mm.x, vv.x, c);
@@ -176,11 +182,10 @@ __global__ void __launch_bounds__(256) adam_multi_dev(float* __restrict__ p, con
             reinterpret_cast<float4*>(M)[i] = mm;
             reinterpret_cast<float4*>(V)[i] = vv;
         }
-        if (blockIdx.x == 0)
+        if (local == 0)
             for (int64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) adam_elem(P[i], G[i], M[i], V[i], c);
     } else {
-        const int64_t stride = int64_t(gridDim.x) * blockDim.x;
-        for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
+        for (int64_t i = int64_t(local) * blockDim.x + threadIdx.x; i < n; i += stride) adam_elem(P[i], G[i], M[i], V[i], c);
     }
     if (own_slots && threadIdx.x == 0) {
         __hip_atomic_store(step + 2 + slot, steps_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -200,29 +205,30 @@ static int lg_adam_multi_group(float* p, const float* g, float* m, float* v, int
     seg.first = first;
     seg.slot_base = slot_base;
     seg.mirror_slot = -1;
-    int64_t longest = 0;
+    int64_t total = 0;
+    seg.wg_base[0] = 0;
     for (int j = 0; j <= nseg; ++j) {
         seg.offsets[j] = offsets[j];
         if (j > 0) {
             LG_ARG(offsets[j] >= offsets[j - 1], "lg_adam_multi_dev_f32: offsets must be non-decreasing");
-            if (offsets[j] - offsets[j - 1] > longest) longest = offsets[j] - offsets[j - 1];
+            total += (offsets[j] - offsets[j - 1] + 1023) / 1024;          // one workgroup per 1024 elements (four per thread)
+            LG_ARG(total < (int64_t(1) << 22), "lg_adam_multi_dev_f32: bucket too large for one launch");
+            seg.wg_base[j] = int(total);
         }
     }
     *slots_used = 0;
-    if (longest == 0) return LG_OK;
+    if (total == 0) return LG_OK;
     const AdamScalars c = adam_scalars(lr, b1, b2, eps, 0.0, 0.0, gscale, belief);
-    // sized for four elements per thread (segments that do not start on a 16-byte boundary loop: grid-stride)
     const int base_aligned = (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) ? 1 : 0;
-    const int64_t grid_x = stream_grid((longest + 3) / 4);
-    *slots_used = int(grid_x) * nseg;
+    *slots_used = int(total);
     if (step_slots > 0) {
         LG_ARG(slot_base + *slots_used <= step_slots, "lg_adam_multi_dev_f32: the grid spans %d step slots, the caller gave %lld (lghip.h)",
                slot_base + *slots_used, (long long)step_slots);
-        if (!*mirrored)                                   // workgroup (0, j) of the first non-empty parameter keeps step[0] current
+        if (!*mirrored)                                   // the first workgroup of the first non-empty parameter keeps step[0] current
             for (int j = 0; j < nseg; ++j)
-                if (offsets[j + 1] > offsets[j]) { seg.mirror_slot = slot_base + j * int(grid_x); *mirrored = true; break; }
+                if (offsets[j + 1] > offsets[j]) { seg.mirror_slot = slot_base + seg.wg_base[j]; *mirrored = true; break; }
     }
-    hipLaunchKernelGGL(adam_multi_dev, dim3(unsigned(grid_x), nseg), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
+    hipLaunchKernelGGL(adam_multi_dev, dim3(unsigned(total)), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, b1, b2,
                        step_slots > 0 ? 1 : 0, base_aligned);
     LG_CHECK_LAUNCH();
     return LG_OK;

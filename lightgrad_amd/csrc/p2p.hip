@@ -238,7 +238,7 @@ struct P2PSegments {
     int     nseg, nseg_total, first;             // as AdamSegments (optim.hip)
     int     pieces;                              // 1024-float pieces per workgroup
     int     total_chunks;                        // workgroups with work in this launch
-    int     chunk_base[kP2PMaxSegments];         // index of a segment's first chunk among the launch's chunks
+    int     chunk_base[kP2PMaxSegments + 1];     // index of a segment's first chunk among the launch's chunks; [nseg] = all of them
     int64_t offsets[kP2PMaxSegments + 1];
 };
 
@@ -246,11 +246,13 @@ __global__ void __launch_bounds__(256) adam_multi_p2p(float* __restrict__ p, flo
                                                       P2PSegments seg, AdamScalars c, int64_t* __restrict__ step, int step_slot_base, double b1, double b2,
                                                       int base_aligned, P2PCtx x) {
     __shared__ float inv_bias[2];
-    const int j = blockIdx.y;
+    // compact grid: one workgroup per chunk with work (a 2-D grid as wide as the longest parameter needs dispatches mostly
+    // workgroups that return at once: optim.hip, AdamSegments)
+    const int chunk = blockIdx.x;
+    int j = 0;
+    while (j + 1 < seg.nseg && chunk >= seg.chunk_base[j + 1]) ++j;  // uniform: scalar loads
     const int64_t begin = seg.offsets[j], end = seg.offsets[j + 1];
-    const int64_t first = begin + int64_t(blockIdx.x) * seg.pieces * kPiece;
-    if (first >= end) return;                                      // workgroup-uniform
-    const int chunk = seg.chunk_base[j] + blockIdx.x;
+    const int64_t first = begin + int64_t(chunk - seg.chunk_base[j]) * seg.pieces * kPiece;
     const int epoch = next_epoch(__hip_atomic_load(x.local + kEpochBase + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     int64_t* my_step = step + 2 + step_slot_base + chunk;          // this workgroup's own copy of the optimizer's step number
     int64_t steps_done = 0;
@@ -538,12 +540,12 @@ extern "C" int lg_p2p_adam_multi_dev_f32(float* p, float* g, float* m, float* v,
             seg.chunk_base[j] = total;
             total += int((offsets[first + j + 1] - offsets[first + j] + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece));
         }
+        seg.chunk_base[count] = total;
         seg.total_chunks = total;
         LG_ARG(total <= S.max_chunks, "lg_p2p_adam_multi_dev_f32: %d chunks exceed the window's %d flags", total, S.max_chunks);
-        const unsigned grid_x = unsigned((longest + int64_t(pieces) * kPiece - 1) / (int64_t(pieces) * kPiece));
         LG_ARG(slot_base + total <= step_slots, "lg_p2p_adam_multi_dev_f32: %d chunks need as many step slots, the caller gave %lld (lghip_p2p.h)",
                slot_base + total, (long long)step_slots);
-        hipLaunchKernelGGL(adam_multi_p2p, dim3(grid_x, count), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, slot_base, b1, b2, base_aligned, x);
+        hipLaunchKernelGGL(adam_multi_p2p, dim3(unsigned(total)), dim3(256), 0, rt().stream, p, g, m, v, seg, c, step, slot_base, b1, b2, base_aligned, x);
         LG_CHECK_LAUNCH();
         slot_base += total;
     }

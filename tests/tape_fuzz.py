@@ -20,15 +20,18 @@ import lightgrad_amd as light
 
 
 class Net(light.nn.Module):
-    def __init__(self, dims, biases):
+    def __init__(self, dims, biases, norms=None):
         light.nn.Module.__init__(self)
         self.layers = light.nn.ModuleList(*[light.nn.Linear(a, b, bias=bias) for a, b, bias in zip(dims[:-1], dims[1:], biases)])
+        norms = norms or [False] * (len(dims) - 1)
+        self.norms = light.nn.ModuleList(*[light.nn.LayerNorm(b) if on else light.nn.Module() for b, on in zip(dims[1:], norms)])
 
 
 def draw_program(seed):
     """the random choices of one program, independent of the backend"""
     rng = np.random.RandomState(seed)
-    depth = int(rng.randint(1, 4))
+    deep = seed % 4 == 3                             # every fourth program is deep enough for the queued weight gradients (GradGroup)
+    depth = int(rng.randint(5, 8)) if deep else int(rng.randint(1, 4))
     batch = int(rng.choice([1, 3, 8, 32, 33, 64, 200]))
     dims = [int(rng.choice([4, 8, 12, 20, 48, 64, 100]))]
     for k in range(depth):
@@ -42,7 +45,8 @@ def draw_program(seed):
         "peek": [bool(rng.rand() < 0.25) for _ in range(depth)],           # read an intermediate mid-forward
         "poke_input": [bool(rng.rand() < 0.15) for _ in range(depth)],     # write into the input in place mid-forward
         "view_in": str(rng.choice(["plain", "plain", "reshape", "transposed"])),
-        "loss": str(rng.choice(["mse", "mse", "sum", "weighted"])),
+        "norm": [bool(deep and rng.rand() < 0.5 and dims[k + 1] >= 4) for k in range(depth)],      # nn.LayerNorm behind the layer
+        "loss": str(rng.choice(["mse", "mse", "sum", "weighted", "ce"])) if dims[-1] >= 2 else "mse",
         "optimizer": str(rng.choice(["sgd", "adam", "adabelief", "adabelief"])),
         "fused": bool(rng.rand() < 0.6), "device_step": bool(rng.rand() < 0.5),
         "steps": int(rng.randint(1, 4)),
@@ -60,7 +64,7 @@ def run_program(T, prog, dtype=np.float32, prepare=None):
     rng = np.random.RandomState(1000 + prog["seed"])
     batch, dims = prog["batch"], prog["dims"]
     np.random.seed(prog["seed"])                     # nn.Linear draws its weights from numpy's global stream
-    model = Net(dims, prog["biases"])
+    model = Net(dims, prog["biases"], prog["norm"])
     w0 = [(n, p.numpy().astype(dtype)) for n, p in model.named_parameters()]
     model.load_parameters(w0)
     if T is not light.CpuTensor:
@@ -69,6 +73,7 @@ def run_program(T, prog, dtype=np.float32, prepare=None):
     target_np = rng.uniform(-1, 1, (batch, dims[-1])).astype(dtype)
     w_np = rng.uniform(-1, 1, (batch, dims[-1])).astype(dtype)
     poke_np = rng.uniform(-1, 1, (batch, dims[0])).astype(dtype)
+    labels_np = rng.randint(0, dims[-1], batch).astype(np.int64)
 
     def make_opt(params):
         kind = prog["optimizer"]
@@ -99,6 +104,8 @@ def run_program(T, prog, dtype=np.float32, prepare=None):
             act = prog["acts"][k]
             if act != "none":
                 h = getattr(h, act)()
+            if prog["norm"][k]:
+                h = model.norms[k](h)
             if prog["residual"][k] and prev.shape == h.shape:
                 h = h + prev
             if prog["scale"][k] is not None:
@@ -115,6 +122,8 @@ def run_program(T, prog, dtype=np.float32, prepare=None):
             return light.loss.mse(h, T.from_numpy(target_np, requires_grad=False))
         if prog["loss"] == "sum":
             return h.sum()
+        if prog["loss"] == "ce":
+            return light.loss.cross_entropy(h, T.from_numpy(labels_np, requires_grad=False))
         return (h * T.from_numpy(w_np, requires_grad=False)).sum()
 
     for step in range(prog["steps"]):

@@ -67,7 +67,7 @@ def test_random_programs_replayed_from_a_graph(hip):
 
         def build():
             np.random.seed(seed)
-            model = Net(prog["dims"], prog["biases"]).map_parameters(lambda p: p.hip())
+            model = Net(prog["dims"], prog["biases"], prog["norm"]).map_parameters(lambda p: p.hip())
             cls = light.optim.Adam if prog["optimizer"] == "adam" else light.optim.AdaBelief
             opt = cls(model.parameters(), lr=1e-2, eps=1e-3, fused=True, device_step=True)
             x, t = hip.from_numpy(x_np, requires_grad=prog["x_requires_grad"]), hip.from_numpy(t_np, requires_grad=False)
@@ -78,6 +78,8 @@ def test_random_programs_replayed_from_a_graph(hip):
                     h = layer(h)
                     if prog["acts"][k] != "none":
                         h = getattr(h, prog["acts"][k])()
+                    if prog["norm"][k]:
+                        h = model.norms[k](h)
                 loss = light.loss.mse(h, t)
                 opt.zero_grad()
                 loss.backward()

@@ -55,6 +55,10 @@ def draw_program(seed):
         "x_requires_grad": bool(rng.rand() < 0.7),
         "seed": int(seed),
     }
+    if prog["norm"][-1] and prog["loss"] == "sum":
+        # the sum over a freshly normalised row is 0 in exact arithmetic: the loss and every gradient behind it would be rounding
+        # noise (which AdaBelief then normalises into steps of size lr) - nothing two correct backends have to agree on
+        prog["loss"] = "weighted"
     return prog
 
 

@@ -87,9 +87,10 @@ __global__ void __launch_bounds__(256) red_rows_wave(const float* __restrict__ i
 }
 
 template <int OP>
-__global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ in, float* __restrict__ partial, RedDesc d,
-                                                      int64_t seg) {
+__global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ in, float* out, float* partial, int* tickets,
+                                                      RedDesc d, int64_t seg) {
     __shared__ float wsum[4];
+    __shared__ int arrived_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = blockIdx.y, split = blockIdx.x, splits = gridDim.x;
     const int64_t begin = split * seg;
@@ -118,11 +119,48 @@ __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ 
     float acc = wave_reduce<OP>(Red<OP>::comb(acc0, acc1));
     if (lane == 0) wsum[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0)
-    {
+    if (splits == 1) {
+        if (threadIdx.x == 0) {
+            const float v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
+            out[row] = d.accumulate ? out[row] + v : v;
+        }
+        return;
+    }
+    // several workgroups per row: publish the partial (write-through, drained), take the row's ticket; the workgroup that
+    // arrives last folds the row's partials in a fixed tree - the second pass of a two-launch reduction, inside this launch
+    if (threadIdx.x == 0) {
         const float v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
-        float* dst = partial + row * splits + split;
-        *dst = d.accumulate ? *dst + v : v;
+        __hip_atomic_store(partial + row * splits + split, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* ticket = tickets + row;
+        const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = order == int(splits) - 1;
+        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived_last = last;
+    }
+    __syncthreads();
+    if (!arrived_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const float* q = partial + row * splits;
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = Red<OP>::identity();
+    int64_t r = threadIdx.x;
+    for (; r + 768 < splits; r += 1024) {                     // four partials in flight per thread
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = __hip_atomic_load(q + r + 256 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = Red<OP>::comb(f[e], x[e]);
+    }
+    for (; r < splits; r += 256) f[0] = Red<OP>::comb(f[0], __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float v = wave_reduce<OP>(Red<OP>::comb(Red<OP>::comb(f[0], f[1]), Red<OP>::comb(f[2], f[3])));
+    __syncthreads();                                          // wsum is read above by thread 0 only, before the barrier it set arrived_last behind
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
+        out[row] = d.accumulate ? out[row] + v : v;
     }
 }
 
@@ -340,20 +378,18 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
             return LG_OK;
         }
         if (splits == 1) {
-            hipLaunchKernelGGL((red_rows_split<OP>), dim3(1, unsigned(d.n_out)), dim3(256), 0, s, in, out, d, seg);
+            hipLaunchKernelGGL((red_rows_split<OP>), dim3(1, unsigned(d.n_out)), dim3(256), 0, s, in, out, nullptr, nullptr, d, seg);
+            return LG_OK;
+        }
+        if (d.n_out > rt().n_gemm_tickets) {   // one ticket per row (n_out < 256 on this path; the pool is far larger)
+            hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, in, out, d);
             return LG_OK;
         }
         float* partial = nullptr;
         int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
         if (rc != LG_OK) return rc;
-        RedDesc d1 = d;
-        d1.accumulate = 0;
-        hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, partial, d1, seg);
-        RedDesc d2{};
-        d2.accumulate = d.accumulate;
-        d2.nk = 1; d2.nr = 1; d2.n_out = d.n_out; d2.rlen = splits;
-        d2.kshape[0] = d.n_out; d2.kstride[0] = splits; d2.rshape[0] = splits; d2.rstride[0] = 1;
-        hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, partial, out, d2);
+        hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, out, partial,
+                           rt().gemm_tickets, d, seg);
         return lg_free(partial);   // stream-ordered: the block is only reused by later launches
     }
 

@@ -86,9 +86,10 @@ __global__ void __launch_bounds__(256) red_rows_wave(const float* __restrict__ i
     if (lane == 0) out[row] = d.accumulate ? out[row] + acc : acc;
 }
 
+constexpr int kRowsFoldGroup = 32;     // segments per first-level ticket (<= 64: folded by one wave)
 template <int OP>
 __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ in, float* out, float* partial, int* tickets,
-                                                      RedDesc d, int64_t seg) {
+                                                      RedDesc d, int64_t seg, int64_t tstride) {
     __shared__ float wsum[4];
     __shared__ int arrived_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,42 +127,48 @@ __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ 
         }
         return;
     }
-    // several workgroups per row: publish the partial (write-through, drained), take the row's ticket; the workgroup that
-    // arrives last folds the row's partials in a fixed tree - the second pass of a two-launch reduction, inside this launch
+    // several workgroups per row: the second pass of a two-launch reduction, inside this launch.  A workgroup publishes its
+    // partial (write-through, drained) and takes a ticket.  ONE ticket for all 768 workgroups of a full sum costs more than the
+    // launch it saves - atomics on one address are served one after the other, 13 ns each (64 MiB: 14.2 -> 23.9 us,
+    // profiles/r4/hbm_sum_single_ticket.txt) - so the fold has two levels: groups of kRowsFoldGroup consecutive segments with a
+    // ticket each (on cache lines of their own); a group's last arriver folds the group and takes the row's ticket; the last
+    // of those folds the groups.  Fixed trees at both levels: bit-reproducible.
+    const int64_t groups = (splits + kRowsFoldGroup - 1) / kRowsFoldGroup, grp = split / kRowsFoldGroup;
+    const int64_t in_group = (grp == groups - 1) ? splits - grp * kRowsFoldGroup : kRowsFoldGroup;
+    float* const partial2 = partial + int64_t(gridDim.y) * splits;              // [row][group]
+    int* const t1 = tickets + (row * (groups + 1) + grp) * tstride;
+    int* const t2 = tickets + (row * (groups + 1) + groups) * tstride;
     if (threadIdx.x == 0) {
         const float v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
         __hip_atomic_store(partial + row * splits + split, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int* ticket = tickets + row;
-        const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = order == int(splits) - 1;
-        if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = __hip_atomic_fetch_add(t1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == int(in_group) - 1;
+        if (last) __hip_atomic_store(t1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         arrived_last = last;
     }
     __syncthreads();
     if (!arrived_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const float* q = partial + row * splits;
-    float f[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f[e] = Red<OP>::identity();
-    int64_t r = threadIdx.x;
-    for (; r + 768 < splits; r += 1024) {                     // four partials in flight per thread
-        float x[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = __hip_atomic_load(q + r + 256 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] = Red<OP>::comb(f[e], x[e]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wave == 0) {                                          // in_group <= 64 partials: one per lane of the first wave
+        const float x = lane < in_group ? __hip_atomic_load(partial + row * splits + grp * kRowsFoldGroup + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : Red<OP>::identity();
+        const float v = wave_reduce<OP>(x);
+        if (lane == 0) {
+            __hip_atomic_store(partial2 + row * groups + grp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int last = __hip_atomic_fetch_add(t2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == int(groups) - 1;
+            if (last) __hip_atomic_store(t2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived_last = last;
+        }
     }
-    for (; r < splits; r += 256) f[0] = Red<OP>::comb(f[0], __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    float v = wave_reduce<OP>(Red<OP>::comb(Red<OP>::comb(f[0], f[1]), Red<OP>::comb(f[2], f[3])));
-    __syncthreads();                                          // wsum is read above by thread 0 only, before the barrier it set arrived_last behind
-    if (lane == 0) wsum[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        v = Red<OP>::comb(Red<OP>::comb(wsum[0], wsum[1]), Red<OP>::comb(wsum[2], wsum[3]));
-        out[row] = d.accumulate ? out[row] + v : v;
-    }
+    if (!arrived_last || wave != 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float f = Red<OP>::identity();
+    for (int64_t r = lane; r < groups; r += 64)
+        f = Red<OP>::comb(f, __hip_atomic_load(partial2 + row * groups + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    f = wave_reduce<OP>(f);
+    if (lane == 0) out[row] = d.accumulate ? out[row] + f : f;
 }
 
 // ---- cols / general: one thread per output element --------------------------------------------
@@ -378,18 +385,21 @@ static int run_reduce(const float* in, float* out, RedDesc& d) {
             return LG_OK;
         }
         if (splits == 1) {
-            hipLaunchKernelGGL((red_rows_split<OP>), dim3(1, unsigned(d.n_out)), dim3(256), 0, s, in, out, nullptr, nullptr, d, seg);
+            hipLaunchKernelGGL((red_rows_split<OP>), dim3(1, unsigned(d.n_out)), dim3(256), 0, s, in, out, nullptr, nullptr, d, seg, int64_t(1));
             return LG_OK;
         }
-        if (d.n_out > rt().n_gemm_tickets) {   // one ticket per row (n_out < 256 on this path; the pool is far larger)
+        const int64_t groups = (splits + kRowsFoldGroup - 1) / kRowsFoldGroup, n_tickets = d.n_out * (groups + 1);
+        if (n_tickets > rt().n_gemm_tickets) {   // (n_out < 256 on this path and a few dozen groups: the pool is far larger)
             hipLaunchKernelGGL((red_rows_wave<OP>), dim3(unsigned((d.n_out + 3) / 4)), dim3(256), 0, s, in, out, d);
             return LG_OK;
         }
+        int64_t tstride = rt().n_gemm_tickets / n_tickets;          // tickets on cache lines of their own while the pool allows
+        if (tstride > 32) tstride = 32;
         float* partial = nullptr;
-        int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * splits) * sizeof(float));
+        int rc = lg_malloc(reinterpret_cast<void**>(&partial), size_t(d.n_out * (splits + groups)) * sizeof(float));
         if (rc != LG_OK) return rc;
         hipLaunchKernelGGL((red_rows_split<OP>), dim3(unsigned(splits), unsigned(d.n_out)), dim3(256), 0, s, in, out, partial,
-                           rt().gemm_tickets, d, seg);
+                           rt().gemm_tickets, d, seg, tstride);
         return lg_free(partial);   // stream-ordered: the block is only reused by later launches
     }
 

@@ -422,6 +422,21 @@ int lg_attention_bwd_f32(const float* q, int64_t ldq, int64_t sbq, const float* 
  * products must not read each other's outputs. */
 int lg_gemm_pair_begin(void);
 int lg_gemm_pair_end(void);
+/* THREE products in one launch: two of the first kind followed by one of the second - the backward pass of
+ * `Linear -> relu -> skinny Linear -> mse` once the hidden layer's gradient exists: dW2 (+ db2) = err^T @ relu(pre) of the skinny
+ * output layer (a skinny first-kind product takes the 64x64 tile inside a collecting bracket), then the hidden layer's dW1 (+ db1)
+ * and dx.  The bracket may stay open between the calls (the tape runs relu.backward in between); whatever makes results visible
+ * to the host or to a graph (lg_sync, device-to-host copies, graph launch, the end of a capture) launches what has been
+ * collected so far, as single launches / a pair, and the bracket goes on collecting.
+ * lg_gemm_pair_mse_loss: the scalar loss of lg_head_fwd_f32 ((sum(row_loss) * (1/n)) * 0.5, the value of lg_mse_finalize_f32,
+ * bit for bit) rides as one spare workgroup of that three-product launch; if the bracket ends without one, it is finished by
+ * a launch of its own at lg_gemm_pair_end.  row_loss and loss must stay valid until then. */
+int lg_gemm_pair_mse_loss(const float* row_loss, int64_t rows, int64_t n, float* loss);
+/* lg_gemm_pair_hold: the bracket stops collecting without launching what it has - products issued now run as if there were no
+ * bracket (their results exist when the call returns, as always) - until lg_gemm_pair_resume makes it collect again.  The
+ * caller vouches that nothing issued in between reads or writes what the held products write. */
+int lg_gemm_pair_hold(void);
+int lg_gemm_pair_resume(void);
 
 /* Many weight-gradient products in ONE launch.  Between lg_gemm_group_begin and lg_gemm_group_end, lg_gemm_f32 /
  * lg_gemm_rowsum_f32 calls of the form dW (+ db) = g^T @ x (transA = 1, transB = 0, one matrix, at most 1024 output tiles of

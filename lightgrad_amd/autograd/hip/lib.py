@@ -75,6 +75,9 @@ PROTOTYPES = {
                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lg_gemm_pair_begin": (c_int, []),
     "lg_gemm_pair_end": (c_int, []),
+    "lg_gemm_pair_mse_loss": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
+    "lg_gemm_pair_hold": (c_int, []),
+    "lg_gemm_pair_resume": (c_int, []),
     "lg_gemm_group_begin": (c_int, []),
     "lg_gemm_group_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int]),
     "lg_gemm_group_flush": (c_int, []),

@@ -8,10 +8,11 @@ Nothing here synchronises with the device and nothing falls back to numpy.
 """
 import builtins as _py      # this module defines ops named max / min / sum / pow
 import ctypes
+import os
 import numpy as np
 from ..func import Function
 import weakref
-from .tensor import HipTensor, HipBuffer, GradGroup, contiguous_strides, flush_lazy_readers
+from .tensor import HipTensor, HipBuffer, GradGroup, HeldPair, contiguous_strides, flush_lazy_readers
 from . import lib as _l
 from .lib import i64
 
@@ -1535,14 +1536,22 @@ class linear(Function):
         # data-parallel exchange hangs on the weight gradient's kernel being enqueued the moment it is reported written
         paired = (weight.requires_grad and x.requires_grad and rows > 0 and weight._grad_written_hook is None
                   and (bias is None or bias._grad_written_hook is None))
+        kept = None
         if paired:
-            _l.check(_l.lib().lg_gemm_pair_begin())
+            if HeldPair.resume():
+                # the skinny output layer behind this one left its weight gradient in an open bracket (_head_backward): the two
+                # products below join it - three products and the loss in one launch
+                kept = HeldPair.keep
+                HeldPair.done()
+            else:
+                _l.check(_l.lib().lg_gemm_pair_begin())
         try:
             dw, db = linear._weight_products(x2, weight, bias, want_db, g2, acc_w, acc_b)
             dx, = linear._input_product(x, weight, g2)
         finally:
             if paired:
                 _l.check(_l.lib().lg_gemm_pair_end())
+        del kept
         return (dx, dw, db) if has_bias else (dx, dw)
 
     @staticmethod
@@ -1781,6 +1790,8 @@ def _head_backward(x, src, relu, weight, bias, g2):
     acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
     acc_b = bias._grad_accumulator() if want_db else None
     acc_b = acc_b if (acc_b is not None and acc_b.is_contiguous()) else None
+    if _head_weight_gradient_can_ride(x, src, relu, weight, bias, acc_w, acc_b, want_db):
+        return _head_backward_riding(x, src, relu, weight, bias, g2, acc_w, acc_b, want_db)
     for t in (acc_w, acc_b):
         if t is not None:
             flush_lazy_readers(t)
@@ -1814,6 +1825,66 @@ def _head_backward(x, src, relu, weight, bias, g2):
     if bias is None:
         return dx, (None if acc_w is not None else dw)
     return dx, (None if acc_w is not None else dw), (None if (acc_b is not None or db is None) else db)
+
+
+_HEAD_RIDE = os.environ.get("LIGHTGRAD_HEAD_RIDE", "1") != "0"      # experiments: 0 = head_bwd with its slab workgroups, always
+
+
+def _head_weight_gradient_can_ride(x, src, relu, weight, bias, acc_w, acc_b, want_db) -> bool:
+    """may dW (+ db) of this skinny output layer wait for the backward of the layer in front of it and share ITS launch?  Yes when
+    that layer is a `linear` node whose backward launches dW and dx together (linear._backward, `paired`), when the gradients
+    are ADDED INTO buffers that exist (parameters after zero_grad: nothing to hand back to the tape, nobody reads them before the
+    pass ends) and nobody waits for the moment they are enqueued (DataParallel's hooks) - the MNIST MLP of the headline, and any
+    `Linear -> relu -> Linear(<= 16) -> loss` tail."""
+    if not (_HEAD_RIDE and relu) or HeldPair.held or GradGroup.active or GradGroup.issuing:
+        return False
+    if acc_w is None or (bias is not None and not want_db) or (want_db and acc_b is None) or not x.requires_grad:
+        return False
+    if weight._grad_written_hook is not None or (bias is not None and bias._grad_written_hook is not None):
+        return False
+    node = src._ctx
+    if node is None or node.__class__ is not linear or len(node._parents) > 3 and node._parents[3] is not None:
+        return False
+    x1, w1 = node._parents[0], node._parents[1]
+    b1 = node._parents[2] if len(node._parents) > 2 else None
+    if not (isinstance(x1, HipTensor) and x1.requires_grad and w1.requires_grad and len(x1._shape) == 2 and x1._data is not None):
+        return False
+    if w1._grad_written_hook is not None or (b1 is not None and b1._grad_written_hook is not None):
+        return False
+    return _rowsum_column_is_cheap(weight._shape[0], weight._shape[1])
+
+
+def _head_backward_riding(x, src, relu, weight, bias, g2, acc_w, acc_b, want_db):
+    """_head_backward with the weight gradient leaving later: dx / g_pre from head_bwd's tile workgroups now (the next tape node
+    needs them), dW (+ db) = g^T @ relu(src) prepared as an MFMA product and held (HeldPair) for the launch of the hidden layer's
+    two products; the loss of the forward pass is finished by a spare workgroup of that launch."""
+    rows, hidden = src._shape
+    outs = weight._shape[0]
+    lib = _l.lib()
+    _l.check(lib.lg_gemm_pair_begin())
+    try:
+        _gemm_fused(_swap_last(g2), src, relu_b=True, accumulate_into=acc_w, overwrite=weight._consume_zero_pending(),
+                    want_rowsum=want_db, rowsum_into=acc_b, rowsum_overwrite=want_db and bias._consume_zero_pending())
+        loss = g2._unfinished_loss() if g2._unfinished_loss is not None else None
+        row_loss = loss_out = None
+        if loss is not None and loss._data is None and loss._lazy_source is not None and loss._lazy_source[0] == "mse_rows" \
+                and loss._lazy_source[1]._shape == (rows,) and loss._lazy_source[2] == rows * outs:
+            row_loss, loss_out = loss._lazy_source[1], HipTensor.empty((), requires_grad=False)
+            _l.check(lib.lg_gemm_pair_mse_loss(row_loss.ptr, rows, rows * outs, loss_out.ptr))
+            loss._data, loss._offset, loss._byte_offset, loss._lazy_source = loss_out._data, loss_out._offset, loss_out._byte_offset, None
+            g2._unfinished_loss = None
+    except BaseException:
+        _l.lib().lg_gemm_pair_end()
+        raise
+    HeldPair.hold(reads=(g2, src, row_loss), writes=(acc_w, acc_b, loss_out))
+    dx = HipTensor.empty((rows, hidden))
+    gpre = HipTensor.empty((rows, hidden))
+    _l.check(lib.lg_head_bwd_f32(src.ptr, hidden, 1, g2.ptr, weight.ptr, dx.ptr, gpre.ptr, None, 0, None, 0,
+                                 rows, hidden, outs, None, None))
+    dx._relu_bwd_done = (src, gpre)
+    if len(x._shape) != 2:
+        dx = dx.reshape(*x._shape)
+    return (dx, None) if bias is None else (dx, None, None)
 
 
 gelu = HipTensor.register_op("gelu", _unary_op("gelu", _l.EW_GELU, _l.EW_GELU_BWD, False,

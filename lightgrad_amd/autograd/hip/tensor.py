@@ -135,6 +135,52 @@ class GradGroup(object):
             _l.check(_l.lib().lg_gemm_group_end())
 
 
+class HeldPair(object):
+    """The weight gradient of a skinny output layer (ops._head_backward), prepared and HELD inside the library
+    (lg_gemm_pair_begin ... lg_gemm_pair_hold) until the hidden layer's backward - two tape nodes later - resumes the bracket and
+    sends its own two products along: dW2 (+ db2), dW1 (+ db1), dx and the scalar of the loss leave as ONE launch
+    (sgemm_triple_wgrad2_xgrad).  Nothing else is collected in between.  The held product reads `keep` and writes `touched`
+    later: an in-place writer into any of them (flush_lazy_readers), the end of the backward pass and everything inside the
+    library that shows results to the host launch it first."""
+    held = False
+    touched = set()       # id(HipBuffer) of what the held product reads or writes
+    keep = ()
+
+    @staticmethod
+    def hold(reads, writes):
+        H = HeldPair
+        H.keep = tuple(t for t in reads + writes if t is not None)
+        H.touched = set(id(t._data) for t in H.keep)
+        _l.check(_l.lib().lg_gemm_pair_hold())
+        H.held = True
+
+    @staticmethod
+    def resume() -> bool:
+        """the caller collects into the open bracket and ends it (lg_gemm_pair_end) itself, then calls done()"""
+        if not HeldPair.held:
+            return False
+        _l.check(_l.lib().lg_gemm_pair_resume())
+        return True
+
+    @staticmethod
+    def done():
+        H = HeldPair
+        H.held, H.keep = False, ()
+        H.touched.clear()
+
+    @staticmethod
+    def release():
+        """launch what is held now (a launch of its own)"""
+        if HeldPair.held:
+            HeldPair.done()
+            _l.check(_l.lib().lg_gemm_pair_end())
+
+
+def _pass_ends():
+    HeldPair.release()
+    GradGroup.pass_ends()
+
+
 def flush_lazy_readers(t) -> None:
     """call before any kernel WRITES into storage that already exists (in-place operators, fill, setitem, uploads,
     accumulating epilogues, optimizer updates, collectives): lazy tensors that were defined from the block's current
@@ -143,6 +189,8 @@ def flush_lazy_readers(t) -> None:
     Costs one attribute test when nobody is waiting (the normal case)."""
     if GradGroup.touched and not GradGroup.issuing and id(t._data) in GradGroup.touched:
         GradGroup.flush()              # storage that a queued launch will read or write
+    if HeldPair.held and id(t._data) in HeldPair.touched:
+        HeldPair.release()
     _make_lazy_readers_real(t)
     buf = t._data
     if buf is not None and buf.frozen:
@@ -308,7 +356,7 @@ class HipTensor(AbstractTensor):
     @staticmethod
     def _backward_pass_begins(n_nodes):
         GradGroup.pass_begins(n_nodes)
-        return GradGroup.pass_ends
+        return _pass_ends
 
     def __init__(self, buffer: HipBuffer, shape: tuple, strides: tuple = None, offset: int = 0,
                  dtype: type = np.float32, requires_grad: bool = True):

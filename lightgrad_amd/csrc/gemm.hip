@@ -30,6 +30,7 @@
 #include "gelu_common.h"
 #include "adam_common.h"
 #include "tail_jobs.h"
+#include "mse_finalize.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -208,6 +209,48 @@ __global__ void __launch_bounds__(256) sgemm_pair_wgrad_xgrad(GemmArgs first, Ge
 #undef LG_TILE_OWNS_LDS
 }
 
+// THREE products and the scalar of the loss in one launch: what the backward pass of `Linear -> relu -> skinny Linear -> mse`
+// (the MNIST MLP of the headline) has left to do once the gradient of the hidden layer exists - the head's weight gradient
+// dW2 (+ db2) = err^T @ relu(pre) (10 x 512 over 1024 rows: a handful of tiles, on its own pure launch latency; as slab workgroups
+// of head_bwd a 6.6 us dependent chain in front of everything else), the hidden layer's dW1 (+ db1) = g^T @ x, dx = g @ W1 - and
+// one spare workgroup that finishes the loss of the forward pass (mse_finalize.h).  Workgroups [0, w[0].nwg) the first
+// A^T-form product, then the second, then the K-contiguous-A product, then the loss.  A kernel of its own: the pair's
+// workgroups do not pay for the third argument block.
+int lg_mse_finalize_job(const float* row_loss, int64_t rows, float inv_n, float* loss);     // head.hip
+struct PairFirsts { GemmArgs w[2]; };
+struct LossJob {
+    const float* row_loss;     // [rows] from head_fwd; NULL: no job
+    float*       loss;
+    int64_t      rows;
+    float        inv_n;
+};
+template <int PD>
+__global__ void __launch_bounds__(256) sgemm_triple_wgrad2_xgrad(PairFirsts firsts, GemmArgs second, LossJob job) {
+    constexpr int L1 = gemm_lds_floats<64, 64, 32, false, false, 1>(), L2 = gemm_lds_floats<64, 64, 32, true, false, 1>();
+    __shared__ __attribute__((aligned(16))) float lds[L1 > L2 ? L1 : L2];
+    constexpr int BM = 64, BN = 64, BK = 32, WM = 2, WN = 2, KG = 1, XT = 0;
+    constexpr bool VA = true, VB = true;
+#define LG_TILE_OWNS_LDS 0
+    const int n0w = firsts.w[0].nwg, n1w = firsts.w[1].nwg;
+    if (int(blockIdx.x) < n0w + n1w) {
+        constexpr bool AKC = false, BKC = false;
+        const int which = int(blockIdx.x) >= n0w ? 1 : 0;              // uniform: scalar loads from the chosen block
+        const GemmArgs g = firsts.w[which];
+#define LG_TILE_BID (int(blockIdx.x) - (which ? n0w : 0))
+#include "gemm_tile_body.inc"
+#undef LG_TILE_BID
+    } else if (int(blockIdx.x) < n0w + n1w + second.nwg) {
+        constexpr bool AKC = true, BKC = false;
+        const GemmArgs& g = second;
+#define LG_TILE_BID (int(blockIdx.x) - n0w - n1w)
+#include "gemm_tile_body.inc"
+#undef LG_TILE_BID
+    } else {
+        finalize_loss(job.row_loss, job.rows, job.inv_n, job.loss, lds);
+    }
+#undef LG_TILE_OWNS_LDS
+}
+
 // Up to kGroupMax independent products of ONE layout in one launch: the weight gradients dW (+ db) = g^T @ x of the Linear
 // layers of a deep network (M-contiguous A, N-contiguous B).  Each of them is a small output with a long K - 12 us alone, 7 of
 // them launch, prologue, split-K hand-off and epilogue, with a handful of workgroups on a 256-CU chip; queued during the
@@ -352,29 +395,35 @@ static void launch_layout(const GemmArgs& g, bool va, bool vb) {
 static void lg_debug_timeline_state(unsigned long long* buf, int nwg, int slices, int tiles);
 #endif
 struct PairState {
-    int      active = 0;       // 0: no bracket; 1: collecting; 2: bracket open but no longer collecting
+    int      active = 0;       // 0: no bracket; 1: collecting; 2: bracket open but no longer collecting; 3: HELD (lg_gemm_pair_hold):
+                               //    what has been collected waits, other products launch as if there were no bracket
     int      count = 0;
-    bool     second_bkc = false;     // layout of the second product's B: K-contiguous (g @ v^T of attention) or N-contiguous (g @ W)
-    GemmArgs args[2];
+    bool     second_bkc = false;     // layout of the K-contiguous-A product's B: K-contiguous (g @ v^T of attention) or N-contiguous (g @ W)
+    // what may be collected: [F], [F, S], [F, F], [F, F, S] - F an A^T-form product (M-contiguous A, N-contiguous B: g^T @ x,
+    // probs^T @ dO), S one with a K-contiguous A (g @ W, dS @ k; dO @ v^T).  [F, S] leaves as sgemm_pair_wgrad_xgrad, [F, F, S]
+    // as sgemm_triple_wgrad2_xgrad, anything else as single launches in call order.
+    GemmArgs args[3];
+    bool     is_s[3] = {false, false, false};
+    int64_t  tiles = 0;        // tickets handed out so far
+    LossJob  job{};            // lg_gemm_pair_mse_loss: finished by a spare workgroup of the three-product launch, else by a launch of its own
 };
 static PairState& pair_state() { static PairState p; return p; }
 
-static void pair_launch_single(const GemmArgs& g, int slot) {
+static void pair_launch_single(const GemmArgs& g, bool is_s) {
     dim3 grid(g.nwg), block(256);
     constexpr int PD = kSmallTilePrefetch;
-    if (slot == 0) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, false, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
+    if (!is_s) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, false, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
     else if (pair_state().second_bkc) hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, true, true, true, PD, 1>), grid, block, 0, rt().stream, g);
     else           hipLaunchKernelGGL((sgemm_mfma<64, 64, 32, 2, 2, true, false, true, true, PD, 1>), grid, block, 0, rt().stream, g);
 }
 
-// The K-slice count of the FIRST product of a pair (the weight gradient, the one that splits K) was chosen as if it had the chip
-// to itself; its workgroups share the CUs with the second product's.  Once both are known the count is chosen again from the same
+// The K-slice count of an A^T-form product of a shared launch (the weight gradient, the one that splits K) was chosen as if it had
+// the chip to itself; its workgroups share the CUs with the other products'.  Once all are known the count is chosen again from the same
 // microsecond model with the joint residency: K-tiles per workgroup x (0.43 c + 0.17) us for c = ceil(all workgroups of the launch /
 // CUs) resident per CU, + 1.8 + 0.85 slices for publishing and folding the slabs.  MNIST MLP (104 + 208 tiles, K = 1024): 5 slices
 // instead of 4 (728 workgroups: still three per CU; six would make four): the step 60.6 -> 59.6 us
-// (profiles/r4/pair_slices_sweep2.txt).  Batched first products keep what they have.
-static int pair_retune_first(PairState& P) {
-    GemmArgs& g = P.args[0];
+// (profiles/r4/pair_slices_sweep2.txt).  Batched products keep what they have.
+static int pair_retune(GemmArgs& g, int64_t others_nwg) {
     const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n;
     static const char* pair_slices_env = getenv("LG_GEMM_PAIR_SLICES");      // experiments: the forced counts stay
     if (pair_slices_env || g.nwg != tiles * g.k_slices || g.seg_k || tiles >= 256 || g.K < 128) return LG_OK;
@@ -384,7 +433,7 @@ static int pair_retune_first(PairState& P) {
     int64_t best_sl = g.k_slices;
     double best = 1e30;
     for (int64_t sl = 1; sl <= 64 && (sl == 1 || sl * 2 <= k_tiles); ++sl) {
-        const double per_cu = double(tiles * sl + P.args[1].nwg) / cus;
+        const double per_cu = double(tiles * sl + others_nwg) / cus;
         const double c = per_cu > 1.0 ? double(int64_t(per_cu + 0.999)) : 1.0;
         const double cost = double((k_tiles + sl - 1) / sl) * (c <= 1.0 ? 0.68 : 0.43 * c + 0.17) + (sl > 1 ? 1.8 + 0.85 * double(sl) : 0.0);
         if (cost < best) { best = cost; best_sl = sl; }
@@ -407,8 +456,20 @@ static int pair_retune_first(PairState& P) {
 static int pair_flush(bool keep_collecting) {
     PairState& P = pair_state();
     int rc = LG_OK;
-    if (P.count == 2) {
-        rc = pair_retune_first(P);
+    bool job_done = false;
+    if (P.count == 3) {
+        // (the first product - the skinny head's dW2 - keeps its own slice count: a few tiles whatever it is)
+        rc = pair_retune(P.args[1], int64_t(P.args[0].nwg) + P.args[2].nwg);
+        if (rc != LG_OK) { P.count = 0; return rc; }
+        PairFirsts firsts;
+        firsts.w[0] = P.args[0];
+        firsts.w[1] = P.args[1];
+        const int spare = P.job.loss ? 1 : 0;
+        hipLaunchKernelGGL((sgemm_triple_wgrad2_xgrad<kSmallTilePrefetch>), dim3(P.args[0].nwg + P.args[1].nwg + P.args[2].nwg + spare), dim3(256), 0,
+                           rt().stream, firsts, P.args[2], P.job);
+        job_done = true;
+    } else if (P.count == 2 && P.is_s[1]) {
+        rc = pair_retune(P.args[0], P.args[1].nwg);
         if (rc != LG_OK) { P.count = 0; return rc; }
 #ifdef LG_GEMM_TIMELINE
         if (P.args[0].tl) {
@@ -422,12 +483,14 @@ static int pair_flush(bool keep_collecting) {
         else
             hipLaunchKernelGGL((sgemm_pair_wgrad_xgrad<kSmallTilePrefetch, false>), dim3(P.args[0].nwg + P.args[1].nwg), dim3(256), 0, rt().stream,
                                P.args[0], P.args[1]);
-    } else if (P.count == 1) {
-        pair_launch_single(P.args[0], 0);
+    } else {
+        for (int i = 0; i < P.count; ++i) pair_launch_single(P.args[i], P.is_s[i]);
     }
     for (int i = 0; i < P.count; ++i)
         if (P.args[i].W) { const int r = lg_free(P.args[i].W); if (r != LG_OK) rc = r; }       // stream-ordered: reused by later launches only
     P.count = 0;
+    P.tiles = 0;
+    if (job_done) P.job = LossJob{};
     if (!keep_collecting && P.active) P.active = 2;
     return rc;
 }
@@ -437,13 +500,20 @@ static bool pair_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, in
     PairState& P = pair_state();
     if (P.active != 1) return false;
     const int slot = P.count;
-    // first: M-contiguous A, N-contiguous B (g^T @ x, probs^T @ dO, dS^T @ q); second: K-contiguous A and either kind of B
-    // (g @ W, dS @ k; dO @ v^T).  Batched products (attention: one matrix per (batch, head)) pair like single ones.
-    const bool fits = slot < 2 && va && vb && batch >= 1 && (slot == 0 ? (!akc && !bkc) : akc);
-    const int64_t first_tiles = slot == 1 ? int64_t(P.args[0].tiles_m) * P.args[0].tiles_n * (P.args[0].nwg / (int64_t(P.args[0].tiles_m) * P.args[0].tiles_n * P.args[0].k_slices)) : 0;
-    if (!fits || first_tiles + int64_t(g.tiles_m) * g.tiles_n * batch > rt().n_gemm_tickets) return false;
-    g.tickets = rt().gemm_tickets + first_tiles;           // the two products fold their K-slices with disjoint tickets
-    if (slot == 1) P.second_bkc = bkc;
+    // Batched products (attention: one matrix per (batch, head)) share launches like single ones.
+    const bool f_form = !akc && !bkc, s_form = akc;
+    bool fits = slot < 3 && va && vb && batch >= 1;
+    if (slot == 0)      fits = fits && f_form;
+    else if (slot == 1) fits = fits && !P.is_s[0] && (f_form || s_form);
+    else                fits = fits && !P.is_s[1] && s_form && !bkc && batch == 1 && !g.relu_a && !g.relu_b;
+    // (three share a launch only as single matrices, the third with an N-contiguous B: what the MLP's backward produces)
+    if (slot == 1 && f_form) fits = fits && batch == 1 && P.args[0].nwg == int64_t(P.args[0].tiles_m) * P.args[0].tiles_n * P.args[0].k_slices;
+    const int64_t tiles = int64_t(g.tiles_m) * g.tiles_n * batch;
+    if (!fits || P.tiles + tiles > rt().n_gemm_tickets) return false;
+    g.tickets = rt().gemm_tickets + P.tiles;               // the products fold their K-slices with disjoint tickets
+    P.tiles += tiles;
+    if (s_form) P.second_bkc = bkc;
+    P.is_s[slot] = s_form;
     P.args[slot] = g;
     P.count = slot + 1;
     return true;
@@ -539,6 +609,9 @@ static bool group_try_defer(GemmArgs& g, bool akc, bool bkc, bool va, bool vb, i
 bool gemm_group_is_open() { return group_state().active == 1; }
 
 int gemm_group_flush_pending() {
+    // (a pair bracket that stays open across tape nodes - the skinny head's weight gradient waiting for the hidden layer's
+    // products - holds prepared launches too: whoever is about to look at results gets them launched, the bracket goes on collecting)
+    if (pair_state().count) { const int prc = pair_flush(true); if (prc != LG_OK) return prc; }
     const int rc = group_flush();
     const int rc2 = ln_group_flush_pending();
     return rc != LG_OK ? rc : rc2;
@@ -635,7 +708,7 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         if (group_try_defer(g, akc, bkc, va, vb, batch, grc)) return LG_OK;
         if (grc != LG_OK) return grc;
     }
-    if (pair_state().count) {                         // something else inside a pair bracket: what is pending goes first
+    if (pair_state().count && pair_state().active != 3) {      // something else inside a pair bracket: what is pending goes first
         const int prc = pair_flush(false);
         if (prc != LG_OK) return prc;
     }
@@ -760,7 +833,11 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
     int rc;
     static const char* tile_env = getenv("LG_GEMM_TILE");
     int tile = tile_env ? atoi(tile_env) : -1;
-    if (N <= 32) {
+    if ((M <= 32 || N <= 32) && lg::pair_state().active == 1 && lg::pair_state().count < 3 && !akc && !bkc && batch == 1) {
+        // a skinny A^T-form product inside a collecting bracket (the head's dW2 = err^T @ relu(pre): 10 x 512): the 64x64 tile,
+        // the only one that shares a launch - on its own tile it would be a launch of its own
+        rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);
+    } else if (N <= 32) {
         rc = launch_config<64, 32, 32, 2, 1>(g, akc, bkc, va, vb, batch);
     } else if (M <= 32) {
         rc = launch_config<32, 64, 32, 1, 2>(g, akc, bkc, va, vb, batch);
@@ -890,10 +967,42 @@ extern "C" int lg_gemm_pair_end(void) {
     LG_REQUIRE_INIT();
     PairState& P = lg::pair_state();
     LG_ARG(P.active != 0, "lg_gemm_pair_end: no pair bracket is open");
-    const int rc = lg::pair_flush(true);
+    int rc = lg::pair_flush(true);
     P.active = 0;
+    if (P.job.loss) {           // nothing it could ride on: a launch of its own (the loss never waits beyond the bracket)
+        const int r = lg::lg_mse_finalize_job(P.job.row_loss, P.job.rows, P.job.inv_n, P.job.loss);
+        P.job = lg::LossJob{};
+        if (r != LG_OK) rc = r;
+    }
     if (rc != LG_OK) return rc;
     LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_pair_hold(void) {
+    LG_REQUIRE_INIT();
+    PairState& P = lg::pair_state();
+    LG_ARG(P.active == 1 || P.active == 2, "lg_gemm_pair_hold: no pair bracket is open");
+    if (P.active == 1) P.active = 3;
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_pair_resume(void) {
+    LG_REQUIRE_INIT();
+    PairState& P = lg::pair_state();
+    LG_ARG(P.active != 0, "lg_gemm_pair_resume: no pair bracket is open");
+    if (P.active == 3) P.active = 1;
+    return LG_OK;
+}
+
+extern "C" int lg_gemm_pair_mse_loss(const float* row_loss, int64_t rows, int64_t n, float* loss) {
+    LG_REQUIRE_INIT();
+    PairState& P = lg::pair_state();
+    LG_ARG(P.active != 0, "lg_gemm_pair_mse_loss: no pair bracket is open");
+    LG_ARG(row_loss && loss && rows > 0 && n > 0, "lg_gemm_pair_mse_loss: bad arguments");
+    LG_ARG(P.job.loss == nullptr, "lg_gemm_pair_mse_loss: the bracket already carries a loss");
+    P.job.row_loss = row_loss; P.job.loss = loss; P.job.rows = rows;
+    P.job.inv_n = float(1.0 / double(n));                 // python's `1 / numel` rounded once to fp32 (as lg_mse_finalize_f32)
     return LG_OK;
 }
 

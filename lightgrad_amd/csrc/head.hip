@@ -24,28 +24,12 @@
 // like the tape's ops.
 #include "common.h"
 #include "adam_common.h"
+#include "mse_finalize.h"
 #include <cstdlib>
 
 namespace lg {
 
 __device__ __forceinline__ float relu_keep_nan(float x) { return (x != x) ? x : (x > 0.0f ? x : 0.0f); }   // np.maximum(x, 0)
-
-// (sum_r row_loss[r] * inv_n) * 0.5 by ONE workgroup of 256 threads, always in the same order: thread t takes rows
-// t, t+256, ..., then a butterfly over the wavefront, then the four wavefronts.  Shared by head_bwd's loss workgroup and
-// by mse_finalize, so the loss has the same bits whoever finishes it.
-__device__ __forceinline__ void finalize_loss(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss,
-                                              float* lds4) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 256) {                                   // 256 summing threads whatever the size of the workgroup: one order
-        float v = 0.f;
-        for (int64_t i = tid; i < rows; i += 256) v += row_loss[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) lds4[wave] = v;
-    }
-    __syncthreads();
-    if (tid == 0) loss[0] = (((lds4[0] + lds4[1]) + (lds4[2] + lds4[3])) * inv_n) * 0.5f;
-}
 
 __global__ void __launch_bounds__(256) mse_finalize(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss) {
     __shared__ float lds4[4];
@@ -337,6 +321,15 @@ extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const floa
     LG_CHECK_LAUNCH();
     return LG_OK;
 }
+
+namespace lg {
+// (gemm.hip: the loss a pair bracket carried and found no three-product launch for)
+int lg_mse_finalize_job(const float* row_loss, int64_t rows, float inv_n, float* loss) {
+    hipLaunchKernelGGL(mse_finalize, dim3(1), dim3(256), 0, rt().stream, row_loss, rows, inv_n, loss);
+    LG_CHECK_LAUNCH();
+    return LG_OK;
+}
+}  // namespace lg
 
 extern "C" int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss) {
     LG_REQUIRE_INIT();

@@ -479,6 +479,13 @@ int lg_gemm_group_end(void);
  * kernels.atom (:285-288) and kernels.reduce (:344-368). */
 int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
                     float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs);
+/* lg_head_fwd_f32 that also writes dx[rows, hidden] = err @ w and gpre[rows, hidden] = dx * (x >= 0) (relu != 0): what
+ * lg_head_bwd_f32 writes for g = err, bit for bit - the gradients of the loss with respect to the layer's input and to the
+ * pre-activation when backward() starts at this loss (its seed is 1: loss.py:12 hands `err` on as the output layer's gradient).
+ * Computed while the row of x is in the cache and w in LDS; the caller uses them in the backward pass only if that is how the
+ * pass goes and x, w, err are unchanged by then.  dx and gpre: both NULL (= lg_head_fwd_f32) or both given. */
+int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
+                         float* y, float* err, float* row_loss, float* dx, float* gpre, int64_t rows, int64_t hidden, int64_t outs);
 int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss);
 int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const float* g, const float* w,
                     float* dx, float* gpre, float* dw, int dw_accumulate, float* db, int db_accumulate,

@@ -1510,6 +1510,7 @@ class linear(Function):
         out_f = weight._shape[0]
         g2 = _rows(out_grad, out_f)
         g2._unfinished_loss = out_grad._unfinished_loss        # a view of the same `err` (see head_mse_forward)
+        g2._head_grad_ahead = out_grad._head_grad_ahead
         pre = _lazy_relu_input(x) if g2._shape[0] > 0 else None
         if pre is not None:
             return linear._backward_through_lazy_relu(x, pre, weight, bias, g2)
@@ -1769,9 +1770,24 @@ def head_mse_forward(y, y_hat):
     rows, hidden = x._shape
     outs = weight._shape[0]
     out, err, row_loss = HipTensor.empty(y._shape, requires_grad=False), HipTensor.empty(y._shape), HipTensor.empty((rows,), requires_grad=False)
-    _l.check(_l.lib().lg_head_fwd_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
-                                      out.ptr, err.ptr, row_loss.ptr, rows, hidden, outs))
+    # The tape is recording (y has a node) and relu(x) @ W^T is what y is: the launch also writes relu.backward's result for the
+    # case that backward() starts at this loss - dx = err @ W and g_pre = dx * (x >= 0), 10 multiply-adds per element next to a row that is in
+    # the cache anyway, instead of a launch of its own in the backward pass (head_bwd's tile workgroups: 7.4 us at 1024 x 512).
+    # Whether the backward pass may use it is decided there (_head_grad_ahead_of).
+    dx = gpre = None
+    if relu and _HEAD_GRAD_AHEAD and y._ctx is not None and x._requires_grad and weight._requires_grad and hidden % 4 == 0:
+        dx, gpre = HipTensor.empty((rows, hidden)), HipTensor.empty((rows, hidden), requires_grad=False)
+    _l.check(_l.lib().lg_head_fwd_grad_f32(x.ptr, hidden, 1 if relu else 0, weight.ptr, bias.ptr if bias is not None else None, y_hat.ptr,
+                                           out.ptr, err.ptr, row_loss.ptr, dx.ptr if dx is not None else None,
+                                           gpre.ptr if gpre is not None else None, rows, hidden, outs))
     y._data, y._offset, y._byte_offset, y._lazy_source = out._data, out._offset, out._byte_offset, None           # y is real now
+    if gpre is not None:
+        token = object()
+        for buf in (x._data, weight._data, err._data):
+            if buf.derived is None:
+                buf.derived = {}
+            buf.derived["head_grad"] = token
+        err._head_grad_ahead = (x, weight, dx, gpre, token)
     # the scalar loss stays lazy: the backward launch of this head finishes it (a cross-workgroup sum inside the forward
     # launch would cost 4 us); whoever reads it before that pays one small launch
     loss = HipTensor(None, (), None, 0, _F32)
@@ -1797,7 +1813,8 @@ def _head_backward(x, src, relu, weight, bias, g2):
             flush_lazy_readers(t)
     dw = acc_w if acc_w is not None else HipTensor.empty(weight._shape)
     db = (acc_b if acc_b is not None else HipTensor.empty((outs,))) if want_db else None
-    dx = HipTensor.empty((rows, hidden)) if x.requires_grad else None
+    ahead = _head_grad_ahead_of(g2, src, weight) if (relu and x.requires_grad) else None
+    dx = HipTensor.empty((rows, hidden)) if (x.requires_grad and ahead is None) else None
     gpre = HipTensor.empty((rows, hidden)) if (relu and dx is not None) else None
     # g2 is the `err` of a fused head + mse forward whose scalar loss nobody has looked at yet: finish it in this launch
     loss = g2._unfinished_loss() if g2._unfinished_loss is not None else None
@@ -1818,6 +1835,8 @@ def _head_backward(x, src, relu, weight, bias, g2):
         weight._notify_grad_written()
     if acc_b is not None:
         bias._notify_grad_written()
+    if ahead is not None:
+        dx, gpre = ahead           # written by the forward launch (head_mse_forward): this launch had the weight gradients only
     if gpre is not None:
         dx._relu_bwd_done = (src, gpre)
     if dx is not None and len(x._shape) != 2:
@@ -1828,6 +1847,23 @@ def _head_backward(x, src, relu, weight, bias, g2):
 
 
 _HEAD_RIDE = os.environ.get("LIGHTGRAD_HEAD_RIDE", "1") != "0"      # experiments: 0 = head_bwd with its slab workgroups, always
+_HEAD_GRAD_AHEAD = os.environ.get("LIGHTGRAD_HEAD_GRAD_AHEAD", "1") != "0"      # experiments: 0 = g_pre by the backward pass, always
+
+
+def _head_grad_ahead_of(g2, src, weight):
+    """(dx, relu.backward's result) that the forward launch wrote ahead (head_mse_forward), if they are what this backward pass needs:
+    g2 IS the err of that launch (mse.backward hands it on untouched when its seed is the constant 1), the layer is the same, and
+    nobody has written into err, the pre-activation or the weight since (their storage still carries the launch's token)"""
+    ahead = g2._head_grad_ahead
+    if ahead is None:
+        return None
+    pre, w, dx, gpre, token = ahead
+    if pre is not src or w is not weight:
+        return None
+    for buf in (src._data, weight._data, g2._data):
+        if buf is None or buf.derived is None or buf.derived.get("head_grad") is not token:
+            return None
+    return dx, gpre
 
 
 def _head_weight_gradient_can_ride(x, src, relu, weight, bias, acc_w, acc_b, want_db) -> bool:
@@ -1877,10 +1913,14 @@ def _head_backward_riding(x, src, relu, weight, bias, g2, acc_w, acc_b, want_db)
         _l.lib().lg_gemm_pair_end()
         raise
     HeldPair.hold(reads=(g2, src, row_loss), writes=(acc_w, acc_b, loss_out))
-    dx = HipTensor.empty((rows, hidden))
-    gpre = HipTensor.empty((rows, hidden))
-    _l.check(lib.lg_head_bwd_f32(src.ptr, hidden, 1, g2.ptr, weight.ptr, dx.ptr, gpre.ptr, None, 0, None, 0,
-                                 rows, hidden, outs, None, None))
+    ahead = _head_grad_ahead_of(g2, src, weight)
+    if ahead is not None:
+        dx, gpre = ahead           # nothing to launch: the forward pass wrote both
+    else:
+        dx = HipTensor.empty((rows, hidden))
+        gpre = HipTensor.empty((rows, hidden))
+        _l.check(lib.lg_head_bwd_f32(src.ptr, hidden, 1, g2.ptr, weight.ptr, dx.ptr, gpre.ptr, None, 0, None, 0,
+                                     rows, hidden, outs, None, None))
     dx._relu_bwd_done = (src, gpre)
     if len(x._shape) != 2:
         dx = dx.reshape(*x._shape)

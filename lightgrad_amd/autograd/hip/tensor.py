@@ -416,6 +416,11 @@ class HipTensor(AbstractTensor):
     # yet (`("mse_rows", ...)` above) - the head's backward launch, which receives err as its gradient, finishes it
     _unfinished_loss = None
 
+    # set on the `err` tensor of a fused head + mse forward that also wrote relu.backward's result for the case that backward()
+    # starts at this loss: (pre, weight, dx, gpre, token) - valid while `token` is still registered with the storage of pre, weight and
+    # err (HipBuffer.derived["head_grad"]: any in-place writer drops it), see ops.head_mse_forward / ops._head_backward
+    _head_grad_ahead = None
+
     @property
     def data(self):
         if self._data is None:
@@ -439,6 +444,7 @@ class HipTensor(AbstractTensor):
         elif kind == "linear":
             _, x, weight = self._lazy_source
             out = _ops._gemm(x, _ops._swap_last(weight))
+
         else:
             assert kind == "head"
             _, x, relu, weight, bias = self._lazy_source

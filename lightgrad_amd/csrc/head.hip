@@ -44,6 +44,9 @@ struct HeadFwd {
     float*       y;        // [rows, outs]
     float*       err;      // [rows, outs]
     float*       row_loss; // [rows]
+    float*       gpre;     // [rows, hidden] dense or NULL (relu != 0 only): (err @ W) * (x >= 0) - what head_bwd's tile workgroups would
+                           // write for the gradient `err` itself, i.e. relu.backward's result when the loss is the root of backward()
+    float*       dx;       // [rows, hidden] dense, with gpre: err @ W, the layer's input gradient before the mask
     int64_t      rows, ldx;
     int          hidden, outs, relu;
 };
@@ -78,10 +81,10 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
         float s = 0.f;                                                      // lane j < outs keeps output j
 #pragma unroll
         for (int j = 0; j < OMAX; ++j) s = (lane == j) ? acc[j] : s;
-        float e2 = 0.f;
+        float e2 = 0.f, e = 0.f;
         if (lane < a.outs) {
             const float yv = a.bias ? s + a.bias[lane] : s;
-            const float e = yv + (-a.target[row * a.outs + lane]);
+            e = yv + (-a.target[row * a.outs + lane]);
             a.y[row * a.outs + lane] = yv;
             a.err[row * a.outs + lane] = e;
             e2 = e * e;
@@ -89,6 +92,31 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);          // OMAX <= 16: lanes 0..15
         if (lane == 0) a.row_loss[row] = e2;
+        if (a.gpre) {
+            // the row of head_bwd's g_pre tile for g = err, while the row's pre-activations are in the cache and W is in LDS: the
+            // same chain of fused multiply-adds over j (ascending, from 0) and the same mask - head_bwd's bits
+            float ev[OMAX];
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) ev[j] = __shfl(e, j, 64);
+            float* q = a.gpre + row * a.hidden;
+            float* qd = a.dx + row * a.hidden;
+            for (int k = lane * 4; k < a.hidden; k += 256) {
+                const float4 h = *reinterpret_cast<const float4*>(p + k);
+                float4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j) {
+                    if (j < a.outs) {
+                        const float4 w = *reinterpret_cast<const float4*>(w_lds + j * a.hidden + k);
+                        d.x = __builtin_fmaf(ev[j], w.x, d.x); d.y = __builtin_fmaf(ev[j], w.y, d.y);
+                        d.z = __builtin_fmaf(ev[j], w.z, d.z); d.w = __builtin_fmaf(ev[j], w.w, d.w);
+                    }
+                }
+                *reinterpret_cast<float4*>(qd + k) = d;
+                d.x *= (h.x >= 0.0f ? 1.0f : 0.0f); d.y *= (h.y >= 0.0f ? 1.0f : 0.0f);
+                d.z *= (h.z >= 0.0f ? 1.0f : 0.0f); d.w *= (h.w >= 0.0f ? 1.0f : 0.0f);
+                *reinterpret_cast<float4*>(q + k) = d;
+            }
+        }
     }
 }
 
@@ -109,6 +137,8 @@ struct HeadBwd {
     int          n_tiles;
     int          col_blocks;   // dx tiles per row of tiles
     int          g_dense;      // outs == OMAX and g 16-byte aligned: g is staged with float4 copies
+    int          tile_rows;    // rows of a dx / gpre tile: kHeadRows next to slab workgroups, 64 when the launch has tiles only (four
+                               // times the workgroups: 64 tiles of 256 rows leave three quarters of the chip idle, 7.4 us at 1024 x 512)
     // the optimizer's update of W / b applied by the slab workgroups to the gradient values they are about to store
     // (lg_adam_epilogue_arm, optim.hip); the new W goes to the plan's second buffer - the dx tiles of this launch read the old one
     const AdamPlan* adam_w;
@@ -257,7 +287,8 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
     static_assert(NW * (kSlabCols + 1) >= kHeadCols && kHeadRows * 16 <= CHUNK * OMAX, "LDS reuse");
     const int t = int(blockIdx.x) - a.n_slabs;
     const int cb = t % a.col_blocks;
-    const int64_t r0 = int64_t(t / a.col_blocks) * kHeadRows;
+    const int tile_rows = a.tile_rows;                          // kHeadRows or less (a multiple of TRT)
+    const int64_t r0 = int64_t(t / a.col_blocks) * tile_rows;
     const int tc = tid & 31, tr = tid >> 5;
     const int k = cb * kHeadCols + tc;
     const bool kin = k < a.hidden;
@@ -265,14 +296,14 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
 #pragma unroll
     for (int i = 0; i < kHeadRows / TRT; ++i) {
         const int64_t r = r0 + tr + TRT * i;
-        xv[i] = (a.gpre && r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
+        xv[i] = (a.gpre && TRT * i < tile_rows && r < a.rows && kin) ? a.x[r * a.ldx + k] : 0.f;
     }
     for (int i = tid; i < OMAX * kHeadCols; i += kHeadThreads) {
         const int j = i / kHeadCols, c = i % kHeadCols;
         const int kk = cb * kHeadCols + c;
         w_lds[i] = (j < a.outs && kk < a.hidden) ? a.w[int64_t(j) * a.hidden + kk] : 0.f;
     }
-    for (int i = tid; i < kHeadRows * OMAX; i += kHeadThreads) {
+    for (int i = tid; i < tile_rows * OMAX; i += kHeadThreads) {
         const int rr = i / OMAX, j = i % OMAX;
         g_lds[i] = (j < a.outs && r0 + rr < a.rows) ? a.g[(r0 + rr) * a.outs + j] : 0.f;
     }
@@ -284,7 +315,7 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
     for (int i = 0; i < kHeadRows / TRT; ++i) {
         const int rr = tr + TRT * i;
         const int64_t r = r0 + rr;
-        if (r < a.rows && kin) {
+        if (rr < tile_rows && r < a.rows && kin) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < OMAX; ++j) s = __builtin_fmaf(g_lds[rr * OMAX + j], w[j], s);
@@ -298,9 +329,19 @@ __global__ void __launch_bounds__(kHeadThreads) head_bwd(HeadBwd a) {
 
 using namespace lg;
 
+extern "C" int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
+                                    float* y, float* err, float* row_loss, float* dx, float* gpre, int64_t rows, int64_t hidden, int64_t outs);
+
 extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
                                float* y, float* err, float* row_loss, int64_t rows, int64_t hidden, int64_t outs) {
+    return lg_head_fwd_grad_f32(x, ldx, relu, w, bias, target, y, err, row_loss, nullptr, nullptr, rows, hidden, outs);
+}
+
+extern "C" int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
+                                    float* y, float* err, float* row_loss, float* dx, float* gpre, int64_t rows, int64_t hidden, int64_t outs) {
     LG_REQUIRE_INIT();
+    LG_ARG((dx == nullptr) == (gpre == nullptr), "lg_head_fwd_grad_f32: dx and gpre go together");
+    LG_ARG(gpre == nullptr || (relu && aligned16(gpre) && aligned16(dx)), "lg_head_fwd_grad_f32: gpre is relu.backward's result: it needs relu != 0; dx and gpre 16-byte aligned");
     LG_ARG(rows > 0 && hidden > 0 && outs > 0 && outs <= 16, "lg_head_fwd_f32: need rows > 0, hidden > 0, 1 <= outs <= 16 (got %lld, %lld, %lld)",
            (long long)rows, (long long)hidden, (long long)outs);
     LG_ARG(x && w && target && y && err && row_loss, "lg_head_fwd_f32: NULL pointer");
@@ -308,7 +349,7 @@ extern "C" int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const floa
            "lg_head_fwd_f32: hidden and ldx must be multiples of 4 and x, w 16-byte aligned");
     LG_ARG(outs * hidden * 4 <= 64 * 1024, "lg_head_fwd_f32: W (%lld x %lld) does not fit the 64 KiB LDS stage", (long long)outs, (long long)hidden);
     HeadFwd a{};
-    a.x = x; a.w = w; a.bias = bias; a.target = target; a.y = y; a.err = err; a.row_loss = row_loss;
+    a.x = x; a.w = w; a.bias = bias; a.target = target; a.y = y; a.err = err; a.row_loss = row_loss; a.gpre = gpre; a.dx = dx;
     a.rows = rows; a.ldx = ldx; a.hidden = int(hidden); a.outs = int(outs); a.relu = relu;
     int64_t grid = (rows + 3) / 4;
     if (grid > 1024) grid = 1024;
@@ -358,7 +399,8 @@ extern "C" int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const floa
     a.inv_n = float(1.0 / double(rows * outs));       // python's `1 / numel` rounded once to fp32 (as lg_mse_f32)
     a.n_slabs = dw ? int((hidden + kSlabCols - 1) / kSlabCols) : (db ? 1 : 0);       // the bias gradient alone: slab 0 does it
     a.col_blocks = int((hidden + kHeadCols - 1) / kHeadCols);
-    const int64_t tiles = (dx || gpre) ? int64_t(a.col_blocks) * ((rows + kHeadRows - 1) / kHeadRows) : 0;
+    a.tile_rows = a.n_slabs > 0 ? kHeadRows : 64;
+    const int64_t tiles = (dx || gpre) ? int64_t(a.col_blocks) * ((rows + a.tile_rows - 1) / a.tile_rows) : 0;
     const int64_t grid = a.n_slabs + tiles + (loss ? 1 : 0);
     if (grid == 0) return LG_OK;
     LG_ARG(grid < (int64_t(1) << 30), "lg_head_bwd_f32: problem too large for one launch");

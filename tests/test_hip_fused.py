@@ -562,3 +562,111 @@ def test_tied_table_looked_up_twice_keeps_call_order_in_the_gradient_queues(hip)
     scale = np.abs(grads[CpuTensor]).max()
     np.testing.assert_allclose(grads[hip], grads[CpuTensor], rtol=1e-5, atol=1e-6 * scale)
     assert np.abs(grads[CpuTensor][ids1]).max() > 0
+
+
+def _mlp_pair(hip, seed, d_in=20, d_hid=32, d_out=5, batch=48):
+    np.random.seed(seed)
+    cpu = MLP(d_in, d_hid, d_out)
+    w0 = [(n, p.numpy().copy()) for n, p in cpu.named_parameters()]
+    dev = MLP(d_in, d_hid, d_out)
+    dev.load_parameters(w0)
+    dev.map_parameters(lambda p: p.hip())
+    rng = np.random.RandomState(seed)
+    x = rng.uniform(-1, 1, (batch, d_in)).astype(np.float32)
+    t = rng.uniform(0, 1, (batch, d_out)).astype(np.float32)
+    return cpu, dev, x, t
+
+
+def _grads(model):
+    return {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("scenario", ["plain", "seed_not_one", "weight_written_between", "input_written_between", "forward_twice",
+                                      "no_zero_grad", "backward_inside_no_bucket", "loss_read_first", "x_without_grad"])
+def test_head_gradients_written_ahead_and_riding_weight_gradient(hip, scenario):
+    """`Linear -> relu -> Linear(<= 16) -> mse`: the forward launch writes the head's input gradients ahead, the head's weight
+    gradient rides in the hidden layer's backward launch (ops._head_backward_riding).  Whatever happens between forward and
+    backward, gradients and loss are those of the CPU backend"""
+    from lightgrad_amd.autograd.hip import ops as H
+    from lightgrad_amd.autograd.hip.tensor import HeldPair
+    cpu, dev, x, t = _mlp_pair(hip, 31)
+
+    def run(model, T):
+        tx = T.from_numpy(x.copy(), requires_grad=scenario != "x_without_grad")
+        tt = T.from_numpy(t, requires_grad=False)
+        params = list(model.parameters())
+        if scenario != "no_zero_grad":
+            for p in params:
+                p.zero_grad()
+        if scenario == "forward_twice":
+            light.loss.mse(model(tx), tt)                                 # a forward pass nobody differentiates
+        loss = light.loss.mse(model(tx), tt)
+        if scenario == "weight_written_between":
+            with light.no_grad():
+                model.l2.weight *= 0.5                                    # the gradient is taken at the NEW weight: w is read by backward
+        if scenario == "input_written_between":
+            with light.no_grad():
+                tx *= 0.0                                                 # saved by Linear 1's node: its weight gradient sees zeros
+        if scenario == "loss_read_first":
+            float(loss.item())
+        if scenario == "seed_not_one":
+            (loss * 3.0).backward()
+        else:
+            loss.backward()
+        if scenario == "no_zero_grad":
+            loss2 = light.loss.mse(model(tx), tt)                         # a second pass ADDS to the gradients of the first
+            loss2.backward()
+        g = _grads(model)
+        if tx.requires_grad:
+            g["x"] = tx.grad.numpy().copy()
+        return float(loss.item()), g
+
+    ref_loss, ref = run(cpu, CpuTensor)
+    assert not HeldPair.held
+    got_loss, got = run(dev, hip)
+    assert not HeldPair.held
+    np.testing.assert_allclose(got_loss, ref_loss, rtol=1e-5)
+    assert sorted(got) == sorted(ref)
+    for n in ref:
+        np.testing.assert_allclose(got[n], ref[n], rtol=1e-4, atol=2e-6, err_msg=scenario + " " + n)
+
+
+def test_riding_weight_gradient_is_one_launch_less_and_the_same_numbers(hip):
+    """with and without the two peepholes (LIGHTGRAD_HEAD_RIDE / LIGHTGRAD_HEAD_GRAD_AHEAD): same loss bits, gradients within
+    rounding (the head's dW comes from MFMA tiles instead of head_bwd's slabs), and a captured step has 4 kernels instead of 5"""
+    from lightgrad_amd.autograd.hip import ops as H
+    from lightgrad_amd.autograd.hip.graph import HipGraph
+    results = {}
+    for flags in ((True, True), (True, False), (False, True), (False, False)):
+        saved = H._HEAD_RIDE, H._HEAD_GRAD_AHEAD
+        H._HEAD_RIDE, H._HEAD_GRAD_AHEAD = flags
+        try:
+            _, dev, x, t = _mlp_pair(hip, 32, d_in=784, d_hid=512, d_out=10, batch=1024)
+            opt = light.optim.AdaBelief(dev.parameters(), lr=1e-3, fused=True, device_step=True)
+            tx, tt = hip.from_numpy(x), hip.from_numpy(t, requires_grad=False)
+            box = {}
+
+            def step():
+                opt.zero_grad()
+                loss = light.loss.mse(dev(tx), tt)
+                loss.backward()
+                box["loss"] = loss
+                opt.step()
+            step()                                                         # eager once (allocations)
+            g = HipGraph()
+            with g.capture():
+                step()
+            g.replay()
+            opt.on_graph_replay()
+            results[flags] = dict(kernels=g.kernel_count(), loss=float(box["loss"].item()),
+                                  w=[p.numpy().copy() for p in dev.parameters()])
+            g.destroy()
+        finally:
+            H._HEAD_RIDE, H._HEAD_GRAD_AHEAD = saved
+    base = results[(False, False)]
+    for flags, r in results.items():
+        assert r["loss"] == base["loss"], flags
+        for a, b in zip(r["w"], base["w"]):
+            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6, err_msg=str(flags))
+    assert results[(True, True)]["kernels"] == base["kernels"] - 1, {k: v["kernels"] for k, v in results.items()}
+    assert results[(True, False)]["kernels"] == base["kernels"], {k: v["kernels"] for k, v in results.items()}

@@ -384,3 +384,89 @@ def test_group_queue_edge_cases_through_the_c_abi(hip):
     np.testing.assert_allclose(run(True)[8], 1 + cs_in.numpy().astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
     ref = g1.numpy().astype(np.float64).T @ x1.numpy() + g2.numpy().astype(np.float64).T @ x2.numpy()
     np.testing.assert_allclose(run(True)[0], ref, rtol=1e-5, atol=1e-4)
+
+
+def test_three_products_and_the_loss_in_one_launch_through_the_c_abi(hip):
+    """lg_gemm_pair_*: [skinny dW2 (+ db2) with relu on B, dW1 (+ db1), dx] and the loss of a head forward leave as ONE launch and give
+    the values of single launches; a held bracket (lg_gemm_pair_hold) lets other products pass untouched; lg_sync launches what is
+    held; a bracket that ends without a third product still finishes the loss"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(5)
+    rows, d_in, hid, outs = 1024, 784, 512, 10
+
+    def dev(a):
+        return hip.from_numpy(np.ascontiguousarray(a, np.float32), requires_grad=False)
+
+    err, pre, g1, x, w1 = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((rows, outs), (rows, hid), (rows, hid), (rows, d_in), (hid, d_in)))
+    row_loss = rng.uniform(0, 1, (rows,)).astype(np.float32)
+    terr, tpre, tg1, tx, tw1, trl = (dev(a) for a in (err, pre, g1, x, w1, row_loss))
+
+    def products(dw2, db2, dw1, db1, dx, between=None):
+        # dW2 (+ db2) = err^T @ relu(pre)
+        L.check(lib.lg_gemm_fused_f32(1, 0, outs, hid, rows, terr.ptr, outs, tpre.ptr, hid, dw2.ptr, hid, 0, None, db2.ptr, 0, 0, 1))
+        if between is not None:
+            between()
+        L.check(lib.lg_gemm_rowsum_f32(1, 0, hid, d_in, rows, tg1.ptr, hid, tx.ptr, d_in, dw1.ptr, d_in, 0, db1.ptr, 0))
+        L.check(lib.lg_gemm_f32(0, 0, rows, d_in, hid, tg1.ptr, hid, 0, tw1.ptr, d_in, 0, dx.ptr, d_in, 0, 1, 0))
+
+    def fresh():
+        return [hip.empty(s) for s in ((outs, hid), (outs,), (hid, d_in), (hid,), (rows, d_in))]
+
+    single = fresh()
+    products(*single)
+    loss_ref = hip.empty(())
+    L.check(lib.lg_mse_finalize_f32(trl.ptr, rows, rows * outs, loss_ref.ptr))
+    e64, p64, g64 = err.astype(np.float64), np.maximum(pre, 0).astype(np.float64), g1.astype(np.float64)
+    refs = [e64.T @ p64, e64.sum(0), g64.T @ x.astype(np.float64), g64.sum(0), g64 @ w1.astype(np.float64)]
+    for got, ref in zip(single, refs):
+        np.testing.assert_allclose(got.numpy(), ref, rtol=1e-5, atol=2e-4)
+
+    def same(a, b):
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(u.numpy(), v.numpy(), rtol=2e-6, atol=2e-5)      # (K-slice counts may differ: the sums' order)
+
+    # all three in one bracket, the loss riding
+    one = fresh()
+    loss = hip.empty(())
+    before = L.kernel_launches() if hasattr(L, "kernel_launches") else None
+    L.check(lib.lg_gemm_pair_begin())
+    L.check(lib.lg_gemm_pair_mse_loss(trl.ptr, rows, rows * outs, loss.ptr))
+    products(*one)
+    L.check(lib.lg_gemm_pair_end())
+    same(one, single)
+    np.testing.assert_array_equal(loss.numpy(), loss_ref.numpy())
+    assert lib.lg_gemm_pair_end() != 0                                        # no bracket open any more
+
+    # held across another product (which must see no bracket: it is complete when its call returns)
+    held = fresh()
+    loss2 = hip.empty(())
+    other = hip.empty((rows, d_in))
+    state = {}
+
+    def between():
+        L.check(lib.lg_gemm_pair_mse_loss(trl.ptr, rows, rows * outs, loss2.ptr))
+        L.check(lib.lg_gemm_pair_hold())
+        L.check(lib.lg_gemm_f32(0, 0, rows, d_in, hid, tg1.ptr, hid, 0, tw1.ptr, d_in, 0, other.ptr, d_in, 0, 1, 0))
+        state["other"] = other.numpy().copy()                                  # (a device-to-host copy: launches what is held, too)
+        L.check(lib.lg_gemm_pair_resume())
+    L.check(lib.lg_gemm_pair_begin())
+    products(*held, between=between)
+    L.check(lib.lg_gemm_pair_end())
+    same(held, single)
+    np.testing.assert_allclose(state["other"], single[4].numpy(), rtol=2e-6, atol=2e-5)
+    np.testing.assert_array_equal(loss2.numpy(), loss_ref.numpy())
+
+    # a bracket with the skinny product alone: a launch of its own at the end, and the loss with it
+    alone = fresh()
+    loss3 = hip.empty(())
+    L.check(lib.lg_gemm_pair_begin())
+    L.check(lib.lg_gemm_fused_f32(1, 0, outs, hid, rows, terr.ptr, outs, tpre.ptr, hid, alone[0].ptr, hid, 0, None, alone[1].ptr, 0, 0, 1))
+    L.check(lib.lg_gemm_pair_mse_loss(trl.ptr, rows, rows * outs, loss3.ptr))
+    L.check(lib.lg_gemm_pair_hold())
+    L.check(lib.lg_gemm_pair_end())
+    same(alone[:2], single[:2])
+    np.testing.assert_array_equal(loss3.numpy(), loss_ref.numpy())
+    # hold / resume / loss without a bracket: refused
+    assert lib.lg_gemm_pair_hold() != 0 and lib.lg_gemm_pair_resume() != 0
+    assert lib.lg_gemm_pair_mse_loss(trl.ptr, rows, rows * outs, loss3.ptr) != 0

@@ -374,3 +374,56 @@ def test_loss_read_before_backward_equals_loss_finished_by_backward(hip):
     np.testing.assert_allclose(total.item(), 3.0 * values[0], rtol=1e-6)
     for p, g in zip(model.parameters(), grads):
         np.testing.assert_allclose(p.grad.numpy(), 3.0 * g, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,hidden,outs,with_bias", [(1024, 512, 10, True), (3, 8, 2, True), (65, 36, 7, False), (257, 1024, 16, True), (4100, 64, 10, True)])
+def test_forward_launch_writes_the_backward_tiles_ahead(hip, rows, hidden, outs, with_bias):
+    """lg_head_fwd_grad_f32: dx = err @ W and g_pre = dx * (x >= 0) from the forward launch are lg_head_bwd_f32's for g = err, bit for bit;
+    y / err / row sums are those of lg_head_fwd_f32"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(rows * 3 + hidden + outs)
+    x = rng.uniform(-1, 1, (rows, hidden)).astype(np.float32)
+    x[0, 0], x[0, 1] = 0.0, -0.0
+    w = (rng.uniform(-1, 1, (outs, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    b = rng.uniform(-1, 1, (outs,)).astype(np.float32)
+    t = rng.uniform(0, 1, (rows, outs)).astype(np.float32)
+    tx, tw, tb, tt = (hip.from_numpy(a, requires_grad=False) for a in (x, w, b, t))
+    bp = tb.ptr if with_bias else None
+    y0, e0, r0 = hip.empty((rows, outs)), hip.empty((rows, outs)), hip.empty((rows,))
+    L.check(lib.lg_head_fwd_f32(tx.ptr, hidden, 1, tw.ptr, bp, tt.ptr, y0.ptr, e0.ptr, r0.ptr, rows, hidden, outs))
+    y1, e1, r1 = hip.empty((rows, outs)), hip.empty((rows, outs)), hip.empty((rows,))
+    dx1, gp1 = hip.empty((rows, hidden)), hip.empty((rows, hidden))
+    L.check(lib.lg_head_fwd_grad_f32(tx.ptr, hidden, 1, tw.ptr, bp, tt.ptr, y1.ptr, e1.ptr, r1.ptr, dx1.ptr, gp1.ptr, rows, hidden, outs))
+    for a, c in ((y0, y1), (e0, e1), (r0, r1)):
+        np.testing.assert_array_equal(a.numpy(), c.numpy())
+    dx2, gp2 = hip.empty((rows, hidden)), hip.empty((rows, hidden))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, 1, e0.ptr, tw.ptr, dx2.ptr, gp2.ptr, None, 0, None, 0, rows, hidden, outs, None, None))
+    np.testing.assert_array_equal(dx1.numpy(), dx2.numpy())
+    np.testing.assert_array_equal(gp1.numpy(), gp2.numpy())
+    ref = e0.numpy().astype(np.float64) @ w.astype(np.float64)
+    np.testing.assert_allclose(dx1.numpy(), ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(gp1.numpy(), dx1.numpy() * (x >= 0))
+    # one without the other, or without the relu: refused
+    assert lib.lg_head_fwd_grad_f32(tx.ptr, hidden, 1, tw.ptr, bp, tt.ptr, y1.ptr, e1.ptr, r1.ptr, dx1.ptr, None, rows, hidden, outs) != 0
+    assert lib.lg_head_fwd_grad_f32(tx.ptr, hidden, 0, tw.ptr, bp, tt.ptr, y1.ptr, e1.ptr, r1.ptr, dx1.ptr, gp1.ptr, rows, hidden, outs) != 0
+
+
+@pytest.mark.parametrize("rows", [64, 1000, 1024])
+def test_backward_tiles_alone_use_short_tiles(hip, rows):
+    """lg_head_bwd_f32 without weight gradients (tiles only, 64 rows each) writes what the launch with slabs (256-row tiles) writes"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    hidden, outs = 512, 10
+    rng = np.random.RandomState(rows)
+    x = rng.uniform(-1, 1, (rows, hidden)).astype(np.float32)
+    g = rng.uniform(-1, 1, (rows, outs)).astype(np.float32)
+    w = rng.uniform(-1, 1, (outs, hidden)).astype(np.float32)
+    tx, tg, tw = (hip.from_numpy(a, requires_grad=False) for a in (x, g, w))
+    outs_a = [hip.empty((rows, hidden)) for _ in range(2)]
+    outs_b = [hip.empty((rows, hidden)) for _ in range(2)]
+    dw = hip.empty((outs, hidden))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, 1, tg.ptr, tw.ptr, outs_a[0].ptr, outs_a[1].ptr, None, 0, None, 0, rows, hidden, outs, None, None))
+    L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, 1, tg.ptr, tw.ptr, outs_b[0].ptr, outs_b[1].ptr, dw.ptr, 0, None, 0, rows, hidden, outs, None, None))
+    for a, c in zip(outs_a, outs_b):
+        np.testing.assert_array_equal(a.numpy(), c.numpy())

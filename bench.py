@@ -805,8 +805,9 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
     del c
     # ---- the roofline of the HEADLINE step's own kernels: the two MFMA launches of the MLP step, timed the same
     # way through the C ABI on operands of the step's shapes - the forward product of the first layer (bias epilogue) and the
-    # launch that makes dW1 (+ db1 as row sums) and dx together (lg_gemm_pair_*); the other two launches of the step (the
-    # N = 10 head, forward and backward) move 2 MB and do 10 MFLOP each: launch latency, no roofline to speak of
+    # launch that makes the head's dW2 (+ db2), dW1 (+ db1 as row sums), dx and the loss together (lg_gemm_pair_*); the other
+    # launch of the backward pass' inputs (the N = 10 head's forward, which also writes the head's input gradients) moves 6 MB
+    # and does 20 MFLOP: launch latency, no roofline to speak of
     rs = np.random.RandomState(5 + rank)
     B_, I_, H_ = 1024, 784, 512
     sx = HipTensor.from_numpy(rs.uniform(0, 1, (B_, I_)).astype(np.float32), requires_grad=False)
@@ -814,27 +815,33 @@ def extras(first_losses, args, rank, world, multi, comm, lib, L, light, HipTenso
     sb = HipTensor.from_numpy(rs.uniform(-1, 1, (H_,)).astype(np.float32), requires_grad=False)
     sg = HipTensor.from_numpy(rs.uniform(-1, 1, (B_, H_)).astype(np.float32), requires_grad=False)
     sy, sdw, sdb, sdx = (HipTensor.empty(shape, requires_grad=False) for shape in ((B_, H_), (H_, I_), (H_,), (B_, I_)))
+    O_ = 10
+    serr = HipTensor.from_numpy(rs.uniform(-1, 1, (B_, O_)).astype(np.float32), requires_grad=False)
+    srl = HipTensor.from_numpy(rs.uniform(0, 1, (B_,)).astype(np.float32), requires_grad=False)
+    sdw2, sdb2, sloss = (HipTensor.empty(shape, requires_grad=False) for shape in ((O_, H_), (O_,), ()))
 
     def step_forward():        # pre = x @ W1^T + b1
         L.check(lib.lg_gemm_bias_f32(0, 1, B_, H_, I_, sx.ptr, I_, 0, sw.ptr, I_, 0, sy.ptr, H_, 0, 1, sb.ptr))
 
-    def step_backward():       # dW1 (+ db1) = g^T @ x and dx = g @ W1 in one launch
+    def step_backward():       # dW2 (+ db2) = err^T @ relu(pre), dW1 (+ db1) = g^T @ x, dx = g @ W1 and the loss in one launch
         L.check(lib.lg_gemm_pair_begin())
+        L.check(lib.lg_gemm_fused_f32(1, 0, O_, H_, B_, serr.ptr, O_, sy.ptr, H_, sdw2.ptr, H_, 0, None, sdb2.ptr, 0, 0, 1))
+        L.check(lib.lg_gemm_pair_mse_loss(srl.ptr, B_, B_ * O_, sloss.ptr))
         L.check(lib.lg_gemm_rowsum_f32(1, 0, H_, I_, B_, sg.ptr, H_, sx.ptr, I_, sdw.ptr, I_, 0, sdb.ptr, 0))
         L.check(lib.lg_gemm_f32(0, 0, B_, I_, H_, sg.ptr, H_, 0, sw.ptr, I_, 0, sdx.ptr, I_, 0, 1, 0))
         L.check(lib.lg_gemm_pair_end())
     fwd_us = 1e3 * time_launches(step_forward, 20)
     bwd_us = 1e3 * time_launches(step_backward, 20)
-    fwd_flop, bwd_flop = 2 * B_ * H_ * I_, 2 * 2 * B_ * H_ * I_
+    fwd_flop, bwd_flop = 2 * B_ * H_ * I_, 2 * 2 * B_ * H_ * I_ + 2 * B_ * H_ * O_
     roofline_step = {
-        "kernel": "sgemm_pair_wgrad_xgrad (dW1 + db1 = g^T @ x and dx = g @ W1 in one launch): the dominant kernel of the MLP step",
+        "kernel": "sgemm_triple_wgrad2_xgrad (dW2 + db2 = err^T @ relu(pre), dW1 + db1 = g^T @ x, dx = g @ W1 and the scalar loss in one launch): the dominant kernel of the MLP step",
         "bound": "mfma", "algorithmic_flop_per_launch": bwd_flop, "avg_launch_us": round(bwd_us, 2),
         "achieved": round(bwd_flop / bwd_us / 1e6, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(bwd_flop / bwd_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
         "forward_product": {"kernel": "sgemm_mfma 1024x512x784 NT + bias", "algorithmic_flop_per_launch": fwd_flop, "avg_launch_us": round(fwd_us, 2),
                             "achieved": round(fwd_flop / fwd_us / 1e6, 2), "frac": round(fwd_flop / fwd_us / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)},
         "how": "HIP events on the library stream around 20 back-to-back launches through the C ABI (launch boundaries included), median of 3"}
-    del sx, sw, sb, sg, sy, sdw, sdb, sdx
+    del sx, sw, sb, sg, sy, sdw, sdb, sdx, serr, srl, sdw2, sdb2, sloss
     # HBM-bound kernels of the path, 16384 x 8192 fp32 (512 MiB per tensor: beyond the 256 MiB Infinity Cache).  The
     # operands hold RANDOM data (a 16 MiB random block repeated; constants switch fewer wires and read high)
     big = (16384, 8192)

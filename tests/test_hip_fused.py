@@ -602,11 +602,11 @@ def test_head_gradients_written_ahead_and_riding_weight_gradient(hip, scenario):
             light.loss.mse(model(tx), tt)                                 # a forward pass nobody differentiates
         loss = light.loss.mse(model(tx), tt)
         if scenario == "weight_written_between":
-            with light.no_grad():
-                model.l2.weight *= 0.5                                    # the gradient is taken at the NEW weight: w is read by backward
+            with light.no_grad():                                         # the gradient is taken at the NEW weight: backward reads w
+                model.l2.weight[...] = T.from_numpy(model.l2.weight.numpy() * 0.5, requires_grad=False)
         if scenario == "input_written_between":
-            with light.no_grad():
-                tx *= 0.0                                                 # saved by Linear 1's node: its weight gradient sees zeros
+            with light.no_grad():                                         # saved by Linear 1's node: its weight gradient sees zeros
+                tx[...] = T.from_numpy(np.zeros_like(x), requires_grad=False)
         if scenario == "loss_read_first":
             float(loss.item())
         if scenario == "seed_not_one":

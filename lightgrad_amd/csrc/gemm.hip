@@ -31,6 +31,7 @@
 #include "adam_common.h"
 #include "tail_jobs.h"
 #include "mse_finalize.h"
+#include "head_fwd_body.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -178,6 +179,71 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
 #include "gemm_tile_body.inc"
 #undef LG_TILE_OWNS_LDS
 #undef LG_TILE_BID
+}
+
+// The hidden layer's product and the skinny output layer + loss behind it in ONE launch (lg_gemm_bias_head_fwd_f32):
+// workgroups [0, g.nwg) are the GEMM's tiles (64x32, two K-groups: the forward product of the MNIST MLP's first layer), the
+// rest do head_fwd's rows - four rows each, W2 staged in LDS on arrival - but wait for the tiles of their rows first.  The tiles'
+// stores are write-through and each storing wavefront takes the ticket of its row of tiles when they are drained; a row
+// workgroup polls that ticket (one lane, bounded: 2 s, then the device status flag), reads its rows with sc1 loads and hands
+// the ticket on; the last reader of a row of tiles resets it.  No deadlock: tile workgroups never wait, and row workgroups are
+// dispatched after all of them (each XCD hands out its share of the grid in order).  Saves what a kernel boundary costs
+// between the two (3 us) and the row workgroups' prologue (1.5 us): profiles/r4/README.md.
+struct HeadChain {
+    HeadFwd h;
+    int*    tickets;        // one per row of tiles, `stride` ints apart; zero on entry and on exit
+    int     stride;
+    int     per_row;        // arrivals of tile wavefronts per row of tiles: tiles_n * WM * WN
+    int*    status;
+};
+static const HeadChain*& pending_chain() { static const HeadChain* p = nullptr; return p; }     // set by lg_gemm_bias_head_fwd_f32 around its product
+constexpr int kChainTicketBase = 16384, kChainTicketStride = 32, kChainRowBlocks = 64;      // (pairs / groups count from 0, LayerNorm's queue from the middle)
+template <int OMAX, int PD>
+__global__ void __launch_bounds__(256) sgemm_bias_head_fwd(GemmArgs g, HeadChain c) {
+    constexpr int BM = 64, BN = 32, BK = 32, WM = 2, WN = 1, KG = 2, XT = 0;
+    constexpr bool AKC = true, BKC = true, VA = true, VB = true;
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>()];
+    if (int(blockIdx.x) < g.nwg) {
+        int* const signal_tickets = c.tickets;
+        const int signal_stride = c.stride;
+#define LG_TILE_OWNS_LDS 0
+#define LG_TILE_BID int(blockIdx.x)
+#undef LG_TILE_SIGNAL
+#define LG_TILE_SIGNAL 1
+#include "gemm_tile_body.inc"
+#undef LG_TILE_SIGNAL
+#undef LG_TILE_BID
+#undef LG_TILE_OWNS_LDS
+    } else {
+        const HeadFwd& a = c.h;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wn = a.outs * a.hidden;
+        for (int i = tid * 4; i < wn; i += 1024) *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(a.w + i);
+        const int64_t row0 = int64_t(int(blockIdx.x) - g.nwg) * 4;          // rows row0 .. row0 + 3: one row of tiles (4 divides BM)
+        int* const ticket = c.tickets + int(row0 / BM) * c.stride;
+        const int64_t block_rows = a.rows - (row0 / BM) * BM < BM ? a.rows - (row0 / BM) * BM : BM;
+        const int readers = int((block_rows + 3) / 4);                       // row workgroups of this row of tiles
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.per_row) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ull) {
+                    __hip_atomic_fetch_or(c.status, LG_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            // every reader has seen the tiles once it is here; the last one leaves the ticket at zero for the next launch
+            // (after a give-up the host resets the pool: check_device_status)
+            if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c.per_row) {
+                const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (order == c.per_row + readers - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");              // no instruction: keeps the row's loads below the wait
+        const int64_t row = row0 + wave;
+        if (row < a.rows) head_fwd_row<OMAX, true>(a, lds, row, lane);
+    }
 }
 
 // Two independent products in ONE launch: workgroups [0, first.nwg) work on the first, the rest on the second.  Made for the
@@ -712,6 +778,23 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
         const int prc = pair_flush(false);
         if (prc != LG_OK) return prc;
     }
+    if constexpr (BM == 64 && BN == 32 && WM == 2 && WN == 1 && KG == 2) {
+        if (pending_chain() && akc && bkc && va && vb && batch == 1 && !g.rowsum && !g.addend && !g.act && !g.relu_a && !g.relu_b) {
+            // lg_gemm_bias_head_fwd_f32: the output layer's rows wait at the end of THIS launch
+            HeadChain c = *pending_chain();
+            pending_chain() = nullptr;
+            c.per_row = g.tiles_n * WM * WN;
+            const int row_wgs = int((c.h.rows + 3) / 4);
+            dim3 grid(g.nwg + row_wgs), block(256);
+            constexpr int PD = 2;
+            const int omax = c.h.outs <= 4 ? 4 : (c.h.outs <= 8 ? 8 : (c.h.outs <= 10 ? 10 : 16));
+            if (omax == 4)       hipLaunchKernelGGL((sgemm_bias_head_fwd<4, PD>), grid, block, 0, rt().stream, g, c);
+            else if (omax == 8)  hipLaunchKernelGGL((sgemm_bias_head_fwd<8, PD>), grid, block, 0, rt().stream, g, c);
+            else if (omax == 10) hipLaunchKernelGGL((sgemm_bias_head_fwd<10, PD>), grid, block, 0, rt().stream, g, c);
+            else                 hipLaunchKernelGGL((sgemm_bias_head_fwd<16, PD>), grid, block, 0, rt().stream, g, c);
+            return LG_OK;
+        }
+    }
     if (akc && bkc) launch_layout<BM, BN, BK, WM, WN, true, true, KG>(g, va, vb);
     else if (akc)   launch_layout<BM, BN, BK, WM, WN, true, false, KG>(g, va, vb);
     else if (bkc)   launch_layout<BM, BN, BK, WM, WN, false, true, KG>(g, va, vb);
@@ -919,6 +1002,40 @@ extern "C" int lg_gemm_rowsum_f32(int transA, int transB, int64_t M, int64_t N, 
                                   float* C, int64_t ldc, int accumulate, float* rowsum, int rowsum_accumulate) {
     LG_ARG(rowsum != nullptr, "lg_gemm_rowsum_f32: rowsum is NULL");
     return gemm_impl(transA, transB, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, 1, accumulate, nullptr, rowsum, rowsum_accumulate);
+}
+
+extern "C" int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
+                                    float* y, float* err, float* row_loss, float* dx, float* gpre, int64_t rows, int64_t hidden, int64_t outs);
+
+extern "C" int lg_gemm_bias_head_fwd_f32(const float* x, int64_t ldx, const float* w1, int64_t ldw1, const float* b1, float* pre,
+                                         int64_t rows, int64_t hidden, int64_t d_in, int relu,
+                                         const float* w2, const float* b2, const float* target, float* y, float* err, float* row_loss,
+                                         float* dx, float* gpre, int64_t outs, int* launches) {
+    LG_REQUIRE_INIT();
+    LG_ARG(x && w1 && b1 && pre && w2 && target && y && err && row_loss, "lg_gemm_bias_head_fwd_f32: NULL pointer");
+    LG_ARG(rows > 0 && hidden > 0 && d_in > 0 && outs > 0 && outs <= 16, "lg_gemm_bias_head_fwd_f32: need rows, hidden, d_in > 0 and 1 <= outs <= 16");
+    LG_ARG((dx == nullptr) == (gpre == nullptr) && (gpre == nullptr || relu), "lg_gemm_bias_head_fwd_f32: dx and gpre go together and need relu != 0");
+    LG_ARG(hidden % 4 == 0 && aligned16(pre) && aligned16(w2) && outs * hidden * 4 <= 64 * 1024,
+           "lg_gemm_bias_head_fwd_f32: hidden a multiple of 4, pre and w2 16-byte aligned, w2 within 64 KiB (lg_head_fwd_f32's conditions)");
+    HeadChain c{};
+    c.h.x = pre; c.h.w = w2; c.h.bias = b2; c.h.target = target; c.h.y = y; c.h.err = err; c.h.row_loss = row_loss; c.h.gpre = gpre; c.h.dx = dx;
+    c.h.rows = rows; c.h.ldx = hidden; c.h.hidden = int(hidden); c.h.outs = int(outs); c.h.relu = relu;
+    c.tickets = rt().gemm_tickets + kChainTicketBase;
+    c.stride = kChainTicketStride;
+    c.status = rt().status_dev;
+    // one launch when the rows fit the row workgroups' registers and tickets, W2 fits the LDS the product's tile owns, and the product
+    // resolves to the tile this launch is built on (gemm_impl's cost model: 64x32 with two K-groups); else two launches
+    constexpr int kLdsFloats = gemm_lds_floats<64, 32, 32, true, true, 2>();
+    const bool can_chain = hidden <= 1024 && outs * hidden <= kLdsFloats && rows <= int64_t(kChainRowBlocks) * 64
+                           && kChainTicketBase + kChainRowBlocks * kChainTicketStride <= rt().n_gemm_tickets / 2 && aligned16(dx) && aligned16(gpre);
+    if (can_chain) pending_chain() = &c;
+    const int rc = gemm_impl(0, 1, rows, hidden, d_in, x, ldx, 0, w1, ldw1, 0, pre, hidden, 0, 1, 0, b1);
+    const bool chained = can_chain && pending_chain() == nullptr;
+    pending_chain() = nullptr;
+    if (rc != LG_OK) return rc;
+    if (launches) *launches = chained ? 1 : 2;
+    if (chained) return LG_OK;
+    return lg_head_fwd_grad_f32(pre, hidden, relu, w2, b2, target, y, err, row_loss, dx, gpre, rows, hidden, outs);
 }
 
 extern "C" int lg_gemm_batched2_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,

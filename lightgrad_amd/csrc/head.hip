@@ -25,31 +25,16 @@
 #include "common.h"
 #include "adam_common.h"
 #include "mse_finalize.h"
+#include "head_fwd_body.h"
 #include <cstdlib>
 
 namespace lg {
 
-__device__ __forceinline__ float relu_keep_nan(float x) { return (x != x) ? x : (x > 0.0f ? x : 0.0f); }   // np.maximum(x, 0)
 
 __global__ void __launch_bounds__(256) mse_finalize(const float* __restrict__ row_loss, int64_t rows, float inv_n, float* __restrict__ loss) {
     __shared__ float lds4[4];
     finalize_loss(row_loss, rows, inv_n, loss, lds4);
 }
-
-struct HeadFwd {
-    const float* x;        // [rows, hidden], row pitch ldx
-    const float* w;        // [outs, hidden] dense
-    const float* bias;     // [outs] or NULL
-    const float* target;   // [rows, outs] dense
-    float*       y;        // [rows, outs]
-    float*       err;      // [rows, outs]
-    float*       row_loss; // [rows]
-    float*       gpre;     // [rows, hidden] dense or NULL (relu != 0 only): (err @ W) * (x >= 0) - what head_bwd's tile workgroups would
-                           // write for the gradient `err` itself, i.e. relu.backward's result when the loss is the root of backward()
-    float*       dx;       // [rows, hidden] dense, with gpre: err @ W, the layer's input gradient before the mask
-    int64_t      rows, ldx;
-    int          hidden, outs, relu;
-};
 
 template <int OMAX>
 __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
@@ -58,66 +43,8 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
     const int wn = a.outs * a.hidden;
     for (int i = tid * 4; i < wn; i += 1024) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(a.w + i);
     __syncthreads();
-    for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < a.rows; row += int64_t(gridDim.x) * 4) {
-        float acc[OMAX];
-#pragma unroll
-        for (int j = 0; j < OMAX; ++j) acc[j] = 0.f;
-        const float* p = a.x + row * a.ldx;
-        for (int k = lane * 4; k < a.hidden; k += 256) {
-            float4 h = *reinterpret_cast<const float4*>(p + k);
-            if (a.relu) { h.x = relu_keep_nan(h.x); h.y = relu_keep_nan(h.y); h.z = relu_keep_nan(h.z); h.w = relu_keep_nan(h.w); }
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) {
-                if (j < a.outs) {
-                    const float4 w = *reinterpret_cast<const float4*>(w_lds + j * a.hidden + k);
-                    acc[j] = __builtin_fmaf(h.x, w.x, __builtin_fmaf(h.y, w.y, __builtin_fmaf(h.z, w.z, __builtin_fmaf(h.w, w.w, acc[j]))));
-                }
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
-        float s = 0.f;                                                      // lane j < outs keeps output j
-#pragma unroll
-        for (int j = 0; j < OMAX; ++j) s = (lane == j) ? acc[j] : s;
-        float e2 = 0.f, e = 0.f;
-        if (lane < a.outs) {
-            const float yv = a.bias ? s + a.bias[lane] : s;
-            e = yv + (-a.target[row * a.outs + lane]);
-            a.y[row * a.outs + lane] = yv;
-            a.err[row * a.outs + lane] = e;
-            e2 = e * e;
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);          // OMAX <= 16: lanes 0..15
-        if (lane == 0) a.row_loss[row] = e2;
-        if (a.gpre) {
-            // the row of head_bwd's g_pre tile for g = err, while the row's pre-activations are in the cache and W is in LDS: the
-            // same chain of fused multiply-adds over j (ascending, from 0) and the same mask - head_bwd's bits
-            float ev[OMAX];
-#pragma unroll
-            for (int j = 0; j < OMAX; ++j) ev[j] = __shfl(e, j, 64);
-            float* q = a.gpre + row * a.hidden;
-            float* qd = a.dx + row * a.hidden;
-            for (int k = lane * 4; k < a.hidden; k += 256) {
-                const float4 h = *reinterpret_cast<const float4*>(p + k);
-                float4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < OMAX; ++j) {
-                    if (j < a.outs) {
-                        const float4 w = *reinterpret_cast<const float4*>(w_lds + j * a.hidden + k);
-                        d.x = __builtin_fmaf(ev[j], w.x, d.x); d.y = __builtin_fmaf(ev[j], w.y, d.y);
-                        d.z = __builtin_fmaf(ev[j], w.z, d.z); d.w = __builtin_fmaf(ev[j], w.w, d.w);
-                    }
-                }
-                *reinterpret_cast<float4*>(qd + k) = d;
-                d.x *= (h.x >= 0.0f ? 1.0f : 0.0f); d.y *= (h.y >= 0.0f ? 1.0f : 0.0f);
-                d.z *= (h.z >= 0.0f ? 1.0f : 0.0f); d.w *= (h.w >= 0.0f ? 1.0f : 0.0f);
-                *reinterpret_cast<float4*>(q + k) = d;
-            }
-        }
-    }
+    for (int64_t row = int64_t(blockIdx.x) * 4 + wave; row < a.rows; row += int64_t(gridDim.x) * 4)
+        head_fwd_row<OMAX, false>(a, w_lds, row, lane);
 }
 
 struct HeadBwd {

@@ -76,8 +76,12 @@ int check_device_status(const char* who) {
         return LG_ECOMM;
     }
     if (status & LG_STATUS_HANDOFF_TIMEOUT) {
-        set_error("%s: the attention backward launched earlier gave up waiting for the workgroups it depends on (2 s; device status %d): "
-                  "its gradients are not to be trusted", who, status);
+        // (attention.hip's backward, gemm.hip's product + head rows.  The tickets such a launch leaves behind are not at zero: reset
+        //  the pool so that later launches start clean - the stream is idle here, status is only looked at after a synchronisation)
+        if (R.gemm_tickets) (void)hipMemset(R.gemm_tickets, 0, size_t(R.n_gemm_tickets) * sizeof(int));
+        set_error("%s: a launch whose workgroups wait for other workgroups of the same launch (the attention backward, the hidden layer's "
+                  "product followed by the output layer's rows) gave up waiting (2 s; device status %d): its results are not to be trusted",
+                  who, status);
         return LG_EHIP;
     }
     set_error("%s: a kernel launched earlier met an index or label outside its axis (device status %d); results of that "

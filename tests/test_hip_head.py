@@ -427,3 +427,50 @@ def test_backward_tiles_alone_use_short_tiles(hip, rows):
     L.check(lib.lg_head_bwd_f32(tx.ptr, hidden, 1, tg.ptr, tw.ptr, outs_b[0].ptr, outs_b[1].ptr, dw.ptr, 0, None, 0, rows, hidden, outs, None, None))
     for a, c in zip(outs_a, outs_b):
         np.testing.assert_array_equal(a.numpy(), c.numpy())
+
+
+@pytest.mark.parametrize("rows,d_in,hidden,outs,expect", [
+    (1024, 784, 512, 10, 1),          # the MNIST MLP: one launch
+    (1000, 300, 512, 3, 1),           # a last row of tiles with 40 rows
+    (64, 64, 96, 16, None), (4096, 128, 64, 10, None), (5000, 100, 512, 10, 2), (256, 784, 2048, 4, 2),
+])
+def test_hidden_layer_and_head_in_one_launch(hip, rows, d_in, hidden, outs, expect):
+    """lg_gemm_bias_head_fwd_f32: the bits of lg_gemm_bias_f32 followed by lg_head_fwd_grad_f32, whether it chains the two in one
+    launch or not - and again when launched many times in a row (the tickets go back to zero)"""
+    from lightgrad_amd.autograd.hip import lib as L
+    lib = L.lib()
+    rng = np.random.RandomState(rows + hidden)
+    x = rng.uniform(-1, 1, (rows, d_in)).astype(np.float32)
+    w1 = (rng.uniform(-1, 1, (hidden, d_in)) / np.sqrt(d_in)).astype(np.float32)
+    b1 = rng.uniform(-0.1, 0.1, (hidden,)).astype(np.float32)
+    w2 = (rng.uniform(-1, 1, (outs, hidden)) / np.sqrt(hidden)).astype(np.float32)
+    b2 = rng.uniform(-1, 1, (outs,)).astype(np.float32)
+    t = rng.uniform(0, 1, (rows, outs)).astype(np.float32)
+    tx, tw1, tb1, tw2, tb2, tt = (hip.from_numpy(a, requires_grad=False) for a in (x, w1, b1, w2, b2, t))
+
+    def outputs():
+        return [hip.empty(s) for s in ((rows, hidden), (rows, outs), (rows, outs), (rows,), (rows, hidden), (rows, hidden))]
+    pre0, y0, e0, r0, dx0, gp0 = ref = outputs()
+    L.check(lib.lg_gemm_bias_f32(0, 1, rows, hidden, d_in, tx.ptr, d_in, 0, tw1.ptr, d_in, 0, pre0.ptr, hidden, 0, 1, tb1.ptr))
+    L.check(lib.lg_head_fwd_grad_f32(pre0.ptr, hidden, 1, tw2.ptr, tb2.ptr, tt.ptr, y0.ptr, e0.ptr, r0.ptr, dx0.ptr, gp0.ptr, rows, hidden, outs))
+    np.testing.assert_allclose(pre0.numpy(), x.astype(np.float64) @ w1.astype(np.float64).T + b1, rtol=1e-5, atol=1e-5)
+    n = ctypes.c_int(0)
+    for rep in range(6):
+        got = outputs()
+        for g in got:
+            g.fill(np.nan)
+        pre, y, e, r, dx, gp = got
+        L.check(lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
+                                              y.ptr, e.ptr, r.ptr, dx.ptr, gp.ptr, outs, ctypes.byref(n)))
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a.numpy(), b.numpy())
+        assert n.value in (1, 2) and (expect is None or n.value == expect), n.value
+    hip.synchronize() if hasattr(hip, "synchronize") else None
+    # without the gradients ahead
+    pre, y, e, r, _, _ = got = outputs()
+    L.check(lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
+                                          y.ptr, e.ptr, r.ptr, None, None, outs, None))
+    for a, b in zip(got[:4], ref[:4]):
+        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    assert lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
+                                         y.ptr, e.ptr, r.ptr, dx0.ptr, None, outs, None) != 0

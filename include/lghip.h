@@ -487,15 +487,16 @@ int lg_head_fwd_f32(const float* x, int64_t ldx, int relu, const float* w, const
 int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const float* w, const float* bias, const float* target,
                          float* y, float* err, float* row_loss, float* dx, float* gpre, int64_t rows, int64_t hidden, int64_t outs);
 /* The hidden layer in front of such a head and the head itself: pre = x @ w1^T + b1 ([rows, hidden] dense; x: [rows, d_in] with row
- * pitch ldx, w1: [hidden, d_in] with row pitch ldw1 - nn.Linear's layout), then lg_head_fwd_grad_f32 on pre.  ONE launch when
- * the product resolves to the 64x32 two-K-group tile (the MNIST MLP's 1024 x 512 x 784 does), hidden <= 1024 and rows <= 4096: the
- * head's rows are computed by workgroups at the end of the product's grid, each waiting for the tiles of its rows (written
- * through, announced by a ticket) - a kernel boundary and the head's prologue less; otherwise the two launches.  Same bits
- * either way.  *launches (may be NULL) receives 1 or 2. */
+ * pitch ldx, w1: [hidden, d_in] with row pitch ldw1 - nn.Linear's layout), then lg_head_fwd_grad_f32 on pre: two launches.
+ * chain != 0: ONE launch when the product resolves to the 64x32 two-K-group tile (the MNIST MLP's 1024 x 512 x 784 does),
+ * hidden <= 1024 and rows <= 4096 - the head's rows are computed by workgroups at the end of the product's grid, each waiting
+ * for the tiles of its rows (written through, announced by a flag).  Same bits either way.  An experiment: measured SLOWER than
+ * the two launches on MI355X (22.0 against 20.6 us, profiles/r4/chain_bench.txt) - the tape calls the two launches.
+ * *launches (may be NULL) receives 1 or 2. */
 int lg_gemm_bias_head_fwd_f32(const float* x, int64_t ldx, const float* w1, int64_t ldw1, const float* b1, float* pre,
                               int64_t rows, int64_t hidden, int64_t d_in, int relu,
                               const float* w2, const float* b2, const float* target, float* y, float* err, float* row_loss,
-                              float* dx, float* gpre, int64_t outs, int* launches);
+                              float* dx, float* gpre, int64_t outs, int chain, int* launches);
 int lg_mse_finalize_f32(const float* row_loss, int64_t rows, int64_t n, float* loss);
 int lg_head_bwd_f32(const float* x, int64_t ldx, int relu, const float* g, const float* w,
                     float* dx, float* gpre, float* dw, int dw_accumulate, float* db, int db_accumulate,

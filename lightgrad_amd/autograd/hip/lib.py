@@ -115,7 +115,7 @@ PROTOTYPES = {
                                 c_int64, c_int64, c_int64]),
     "lg_gemm_bias_head_fwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                          POINTER(c_int)]),
+                                          c_int, POINTER(c_int)]),
     "lg_head_fwd_grad_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_int64, c_int64]),
     "lg_head_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

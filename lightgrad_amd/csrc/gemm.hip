@@ -187,8 +187,13 @@ __global__ void __launch_bounds__(WM * WN * KG * 64) sgemm_mfma(GemmArgs g) {
 // stores are write-through and each storing wavefront takes the ticket of its row of tiles when they are drained; a row
 // workgroup polls that ticket (one lane, bounded: 2 s, then the device status flag), reads its rows with sc1 loads and hands
 // the ticket on; the last reader of a row of tiles resets it.  No deadlock: tile workgroups never wait, and row workgroups are
-// dispatched after all of them (each XCD hands out its share of the grid in order).  Saves what a kernel boundary costs
-// between the two (3 us) and the row workgroups' prologue (1.5 us): profiles/r4/README.md.
+// dispatched after all of them (each XCD hands out its share of the grid in order).
+// MEASURED AND NOT USED by the tape (profiles/r4/chain_bench.txt, MNIST MLP shapes, replayed graphs): 22.0 us against 20.6 us for
+// the two launches.  The tiles alone take 14.7 us in this form (13.7 with plain stores and no ticket), and the rows finish 7.3 us
+// after them - as long as head_fwd takes as a kernel of its own, boundary included: a flag that has to travel through memory, rows
+// that have to come from memory (sc1) instead of the L2, and nothing of the rows' work overlaps the tiles'.  What a kernel boundary
+// costs on this chip (3 us) is less than what it takes to pass data between workgroups on different XCDs by hand.  Kept behind
+// `chain = 1` of the entry point, with its parity test.
 struct HeadChain {
     HeadFwd h;
     int*    tickets;        // one per row of tiles, `stride` ints apart; zero on entry and on exit
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(256) sgemm_bias_head_fwd(GemmArgs g, HeadChain
     __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<BM, BN, BK, AKC, BKC, KG>()];
     if (int(blockIdx.x) < g.nwg) {
         int* const signal_tickets = c.tickets;
-        const int signal_stride = c.stride;
+        const int signal_stride = c.stride, signal_per_row = c.per_row;
 #define LG_TILE_OWNS_LDS 0
 #define LG_TILE_BID int(blockIdx.x)
 #undef LG_TILE_SIGNAL
@@ -223,26 +228,34 @@ __global__ void __launch_bounds__(256) sgemm_bias_head_fwd(GemmArgs g, HeadChain
         int* const ticket = c.tickets + int(row0 / BM) * c.stride;
         const int64_t block_rows = a.rows - (row0 / BM) * BM < BM ? a.rows - (row0 / BM) * BM : BM;
         const int readers = int((block_rows + 3) / 4);                       // row workgroups of this row of tiles
+        int* const flag = ticket + 16;                                       // raised by the wavefront that completes the row of tiles
+        int* const done = ticket + 17;                                       // row workgroups that have seen it
+        __shared__ int seen;
         if (tid == 0) {
+            int ok = 1;
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.per_row) {
-                __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(2);
                 if (wall_clock64() - t0 > 200000000ull) {
                     __hip_atomic_fetch_or(c.status, LG_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = 0;
                     break;
                 }
             }
-            // every reader has seen the tiles once it is here; the last one leaves the ticket at zero for the next launch
-            // (after a give-up the host resets the pool: check_device_status)
-            if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= c.per_row) {
-                const int order = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (order == c.per_row + readers - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            seen = ok;
         }
-        __syncthreads();
+        __syncthreads();                                                     // W2 is staged, the rows' tiles are in memory
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");              // no instruction: keeps the row's loads below the wait
         const int64_t row = row0 + wave;
         if (row < a.rows) head_fwd_row<OMAX, true>(a, lds, row, lane);
+        // off the path of the rows' loads: the last row workgroup that has seen the flag lowers it for the next launch (after a
+        // give-up the host resets the pool: check_device_status)
+        if (tid == 0 && seen) {
+            if (__hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == readers - 1) {
+                __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -784,7 +797,8 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
             HeadChain c = *pending_chain();
             pending_chain() = nullptr;
             c.per_row = g.tiles_n * WM * WN;
-            const int row_wgs = int((c.h.rows + 3) / 4);
+            static const char* no_rows_env = getenv("LG_CHAIN_NO_ROWS");           // experiments: the tiles alone (results incomplete)
+            const int row_wgs = (no_rows_env && atoi(no_rows_env) == 1) ? 0 : int((c.h.rows + 3) / 4);
             dim3 grid(g.nwg + row_wgs), block(256);
             constexpr int PD = 2;
             const int omax = c.h.outs <= 4 ? 4 : (c.h.outs <= 8 ? 8 : (c.h.outs <= 10 ? 10 : 16));
@@ -1010,7 +1024,7 @@ extern "C" int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const
 extern "C" int lg_gemm_bias_head_fwd_f32(const float* x, int64_t ldx, const float* w1, int64_t ldw1, const float* b1, float* pre,
                                          int64_t rows, int64_t hidden, int64_t d_in, int relu,
                                          const float* w2, const float* b2, const float* target, float* y, float* err, float* row_loss,
-                                         float* dx, float* gpre, int64_t outs, int* launches) {
+                                         float* dx, float* gpre, int64_t outs, int chain, int* launches) {
     LG_REQUIRE_INIT();
     LG_ARG(x && w1 && b1 && pre && w2 && target && y && err && row_loss, "lg_gemm_bias_head_fwd_f32: NULL pointer");
     LG_ARG(rows > 0 && hidden > 0 && d_in > 0 && outs > 0 && outs <= 16, "lg_gemm_bias_head_fwd_f32: need rows, hidden, d_in > 0 and 1 <= outs <= 16");
@@ -1026,7 +1040,7 @@ extern "C" int lg_gemm_bias_head_fwd_f32(const float* x, int64_t ldx, const floa
     // one launch when the rows fit the row workgroups' registers and tickets, W2 fits the LDS the product's tile owns, and the product
     // resolves to the tile this launch is built on (gemm_impl's cost model: 64x32 with two K-groups); else two launches
     constexpr int kLdsFloats = gemm_lds_floats<64, 32, 32, true, true, 2>();
-    const bool can_chain = hidden <= 1024 && outs * hidden <= kLdsFloats && rows <= int64_t(kChainRowBlocks) * 64
+    const bool can_chain = chain != 0 && hidden <= 1024 && outs * hidden <= kLdsFloats && rows <= int64_t(kChainRowBlocks) * 64
                            && kChainTicketBase + kChainRowBlocks * kChainTicketStride <= rt().n_gemm_tickets / 2 && aligned16(dx) && aligned16(gpre);
     if (can_chain) pending_chain() = &c;
     const int rc = gemm_impl(0, 1, rows, hidden, d_in, x, ldx, 0, w1, ldw1, 0, pre, hidden, 0, 1, 0, b1);

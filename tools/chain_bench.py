@@ -29,11 +29,26 @@ def main():
 
     def one():
         L.check(lib.lg_gemm_bias_head_fwd_f32(x.ptr, d_in, w1.ptr, d_in, b1.ptr, pre.ptr, rows, hidden, d_in, 1, w2.ptr, b2.ptr, t.ptr,
-                                              y.ptr, e.ptr, r.ptr, dx.ptr, gp.ptr, outs, ctypes.byref(n)))
+                                              y.ptr, e.ptr, r.ptr, dx.ptr, gp.ptr, outs, 1, ctypes.byref(n)))
     for rep in range(3):
         a = timed(two, 50) * 1e3
         b = timed(one, 50) * 1e3
         print("product, then head: %.2f us    chained (%d launch): %.2f us" % (a, n.value, b))
+    if os.environ.get("LG_CHAIN_NO_ROWS") == "1":
+        return
+    # inside hipGraphs of 8 repetitions (how the training step runs them)
+    from lightgrad_amd.autograd.hip.graph import HipGraph
+    graphs = []
+    for fn in (two, one):
+        g = HipGraph()
+        with g.capture():
+            for _ in range(8):
+                fn()
+        graphs.append(g)
+    for rep in range(3):
+        a = timed(graphs[0].replay, 20) * 1e3 / 8
+        b = timed(graphs[1].replay, 20) * 1e3 / 8
+        print("replayed graphs of 8:  product, then head: %.2f us    chained: %.2f us" % (a, b))
 
 
 if __name__ == "__main__":

@@ -49,9 +49,12 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="MLP step only: skip matmul / roofline / HBM / BERT / CPU legs")
     ap.add_argument("--no-fused-optimizer", action="store_true", help="run the optimizer as ~14 tape ops per parameter")
     ap.add_argument("--update-in-backward", action="store_true",
-                    help="N = 1: let the backward kernels apply the optimizer's update (optim.Adam.fuse_update_into_backward: 4 launches per "
-                         "step instead of 5, same bits).  Not the default: measured on MI355X it moves the 6 us of the update launch into the "
-                         "tails of the two launches that make the gradients and the step stays where it was (profiles/r4/README.md)")
+                    help="also on the legs of a multi-GPU run that train without the exchange (the default at N = 1, see --no-update-in-backward)")
+    ap.add_argument("--no-update-in-backward", action="store_true",
+                    help="N = 1: launch the optimizer's update as a kernel of its own.  The default lets the backward kernels apply it "
+                         "(optim.Adam.fuse_update_into_backward: 3 launches per step instead of 4, same bits; the parameters alternate between "
+                         "two buckets, so a recorded graph holds an even number of steps): 49.9 against 51.2 us per step on MI355X "
+                         "(profiles/r4/mlp_step_ab_three_products.txt)")
     ap.add_argument("--force-comm", action="store_true",
                     help="exercise the multi-GPU code path (RCCL communicator, forked all-reduce inside the graph) with world_size 1")
     ap.add_argument("--dispatch", choices=["graph", "eager"], default="graph",
@@ -353,10 +356,10 @@ def gpu_rank(args, rank, world):
                                     device_step=use_graph)
         if use_graph:
             dp.attach(opt, exchange_in_optimizer=in_optimizer)        # flat buckets: zero_grad = one flag, update = one launch
-        # --update-in-backward, one GPU (or a rank training alone): the kernels that make the gradients apply the update themselves -
+        # one GPU (or, with --update-in-backward, a rank training alone): the kernels that make the gradients apply the update themselves -
         # no optimizer launch.  The parameters then alternate between two buckets, so every recorded graph holds an even number of steps.
-        in_backward = (use_graph and (not multi or no_exchange) and args.update_in_backward and not args.force_comm
-                       and n_steps % 2 == 0 and min(args.graph_steps, n_steps) >= 2)
+        wanted = (not multi and not args.no_update_in_backward) or (no_exchange and args.update_in_backward)
+        in_backward = (use_graph and wanted and not args.force_comm and n_steps % 2 == 0 and min(args.graph_steps, n_steps) >= 2)
         if in_backward:
             opt.fuse_update_into_backward()
         per_graph = 2 if in_backward else 1                     # steps in the "one step" graph

@@ -13,10 +13,10 @@ shutil.copy(os.path.join(src, "gemm_sweep.txt"), os.path.join(dst, "gemm_sweep_%
 for extra in ("hbm_bench", "mlp_gemm_bench", "head_bench", "gemm_timeline", "pmc_sq_mlp_gemm", "step_gap_one_step_per_graph",
               "step_gap_eight_steps_per_graph", "wrap_summary", "bert_step_trace", "bert_bench", "bert_gemm_bench", "ce_bench", "graph_branch_probe", "soak", "dist_two_ranks_one_gpu",
               "p2p_bench_cu_masked", "p2p_bench_no_mask", "ipc_probe", "gemm_ring_lab_run", "attn_timeline", "mlp_step_ab",
-              "step_trace_update_in_backward"):
+              "step_trace_update_in_backward", "step_trace_optimizer_launch", "chain_bench"):
     if os.path.exists(os.path.join(src, extra + ".txt")):
         shutil.copy(os.path.join(src, extra + ".txt"), os.path.join(dst, "%s_%s.txt" % (extra, tag)))
-for name in ("bench_rehearsal_two_ranks_one_gpu", "bench_rehearsal_rccl_fallback", "bench_rehearsal_under_torchrun", "bench_update_in_backward"):
+for name in ("bench_rehearsal_two_ranks_one_gpu", "bench_rehearsal_rccl_fallback", "bench_rehearsal_under_torchrun", "bench_update_in_backward", "bench_optimizer_launch"):
     if os.path.exists(os.path.join(src, name + ".json")):
         shutil.copy(os.path.join(src, name + ".json"), os.path.join(dst, "%s_%s.json" % (name, tag)))
 pmc = {}

@@ -34,7 +34,8 @@ step rehearse 400 "python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --w
 step rehearsefb 400 "LG_BENCH_FAIL_RCCL=init:1 python bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-extras --comm-open-timeout 5 > $out/bench_rehearsal_rccl_fallback.json 2> $out/bench_rehearsal_rccl_fallback.err"; tail -c 300 $out/bench_rehearsal_rccl_fallback.json
 step torchrun 400 "python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse-on-one-gpu --steps 80 --warmup 10 --no-extras > $out/bench_rehearsal_under_torchrun.json 2> $out/bench_rehearsal_under_torchrun.err"; tail -c 300 $out/bench_rehearsal_under_torchrun.json
 step ab 100 "python tools/mlp_step_ab.py 3 > $out/mlp_step_ab.txt 2>&1"; cat $out/mlp_step_ab.txt
-step traceub 200 "w=\$(mktemp -d /tmp/tr_XXXX); rocprofv3 --kernel-trace --output-format csv -d \$w -- python3 bench.py --steps 400 --warmup 40 --graph-steps 8 --no-extras --update-in-backward > $out/bench_update_in_backward.json 2> $out/traceub.err; python tools/kernel_window.py \$(find \$w -name '*kernel_trace.csv' | head -1) 8 head_fwd > $out/step_trace_update_in_backward.txt; rm -rf \$w"; cat $out/step_trace_update_in_backward.txt
+step traceopt 200 "w=\$(mktemp -d /tmp/tr_XXXX); rocprofv3 --kernel-trace --output-format csv -d \$w -- python3 bench.py --steps 400 --warmup 40 --graph-steps 8 --no-extras --no-update-in-backward > $out/bench_optimizer_launch.json 2> $out/traceopt.err; python tools/kernel_window.py \$(find \$w -name '*kernel_trace.csv' | head -1) 8 head_fwd > $out/step_trace_optimizer_launch.txt; rm -rf \$w"; cat $out/step_trace_optimizer_launch.txt
+step chain 100 "python tools/chain_bench.py > $out/chain_bench.txt 2>&1"; cat $out/chain_bench.txt
 step dist2 300 "python -m pytest tests/test_hip_dist.py -m gpu -q > $out/dist_two_ranks_one_gpu.txt 2>&1"; tail -2 $out/dist_two_ranks_one_gpu.txt
 step p2pbench 200 "python tools/p2p_bench.py 2 > $out/p2p_bench_cu_masked.txt 2>&1; P2P_BENCH_MASK=0 python tools/p2p_bench.py 2 > $out/p2p_bench_no_mask.txt 2>&1"; cat $out/p2p_bench_cu_masked.txt
 step ipcprobe 100 "tools/ipc_probe.bin > $out/ipc_probe.txt 2>&1"; tail -3 $out/ipc_probe.txt

@@ -9,6 +9,9 @@ names = [r["Kernel_Name"] for r in rows]
 # a step of the flat-bucket path ends with its ONE multi-tensor optimizer launch; the per-parameter path has four
 marks = [i for i, n in enumerate(names) if "adam_multi_dev" in n]
 if len(marks) < 60:
+    # the update applied by the backward kernels (bench.py's default at N = 1): a step ends with the launch that makes dW2, dW1 and dx
+    marks = [i for i, n in enumerate(names) if "sgemm_triple_wgrad2_xgrad" in n]
+if len(marks) < 60:
     marks = [i for i, n in enumerate(names) if "adam" in n][3::4]
 s, e = marks[50] + 1, marks[51] + 1
 tot = 0

@@ -47,6 +47,99 @@ __global__ void __launch_bounds__(256) head_fwd(HeadFwd a) {
         head_fwd_row<OMAX, false>(a, w_lds, row, lane);
 }
 
+// The same rows with W in REGISTERS instead of LDS: a lane owns the columns k = 4 lane + 256 c (c < CH) of every row it meets, so it
+// needs exactly those columns of W - OMAX x CH float4, loaded once, next to the first row's loads (one memory latency instead of
+// stage + barrier + row).  No LDS traffic per row (the staged form reads 20 KB of W per row and wavefront).  Same chains of fused
+// multiply-adds in the same order: the staged kernel's bits.
+template <int OMAX, int CH>
+__global__ void __launch_bounds__(256) head_fwd_regs(HeadFwd a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t row = int64_t(blockIdx.x) * 4 + wave;
+    if (row >= a.rows) return;
+    float4 wr[OMAX][CH];
+#pragma unroll
+    for (int j = 0; j < OMAX; ++j)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = lane * 4 + 256 * c;
+            wr[j][c] = (j < a.outs && k < a.hidden) ? *reinterpret_cast<const float4*>(a.w + j * a.hidden + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    for (; row < a.rows; row += int64_t(gridDim.x) * 4) {
+        const float* p = a.x + row * a.ldx;
+        float4 h[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = lane * 4 + 256 * c;
+            h[c] = k < a.hidden ? *reinterpret_cast<const float4*>(p + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float acc[OMAX];
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (lane * 4 + 256 * c < a.hidden) {
+                float4 v = h[c];
+                if (a.relu) { v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); v.z = relu_keep_nan(v.z); v.w = relu_keep_nan(v.w); }
+#pragma unroll
+                for (int j = 0; j < OMAX; ++j)
+                    if (j < a.outs)
+                        acc[j] = __builtin_fmaf(v.x, wr[j][c].x, __builtin_fmaf(v.y, wr[j][c].y, __builtin_fmaf(v.z, wr[j][c].z, __builtin_fmaf(v.w, wr[j][c].w, acc[j]))));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < OMAX; ++j) s = (lane == j) ? acc[j] : s;
+        float e2 = 0.f, e = 0.f;
+        if (lane < a.outs) {
+            const float yv = a.bias ? s + a.bias[lane] : s;
+            e = yv + (-a.target[row * a.outs + lane]);
+            a.y[row * a.outs + lane] = yv;
+            a.err[row * a.outs + lane] = e;
+            e2 = e * e;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) e2 += __shfl_xor(e2, off, 64);
+        if (lane == 0) a.row_loss[row] = e2;
+        if (a.gpre) {
+            float ev[OMAX];
+#pragma unroll
+            for (int j = 0; j < OMAX; ++j) ev[j] = __shfl(e, j, 64);
+            float* q = a.gpre + row * a.hidden;
+            float* qd = a.dx + row * a.hidden;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = lane * 4 + 256 * c;
+                if (k < a.hidden) {
+                    float4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < OMAX; ++j)
+                        if (j < a.outs) {
+                            d.x = __builtin_fmaf(ev[j], wr[j][c].x, d.x); d.y = __builtin_fmaf(ev[j], wr[j][c].y, d.y);
+                            d.z = __builtin_fmaf(ev[j], wr[j][c].z, d.z); d.w = __builtin_fmaf(ev[j], wr[j][c].w, d.w);
+                        }
+                    *reinterpret_cast<float4*>(qd + k) = d;
+                    d.x *= (h[c].x >= 0.0f ? 1.0f : 0.0f); d.y *= (h[c].y >= 0.0f ? 1.0f : 0.0f);
+                    d.z *= (h[c].z >= 0.0f ? 1.0f : 0.0f); d.w *= (h[c].w >= 0.0f ? 1.0f : 0.0f);
+                    *reinterpret_cast<float4*>(q + k) = d;
+                }
+            }
+        }
+    }
+}
+
+template <int OMAX>
+static bool launch_head_fwd_regs(const HeadFwd& a, dim3 grid, hipStream_t s) {
+    const int ch = (a.hidden + 255) / 256;
+    if (ch == 1)                    { hipLaunchKernelGGL((head_fwd_regs<OMAX, 1>), grid, dim3(256), 0, s, a); return true; }
+    if (ch == 2)                    { hipLaunchKernelGGL((head_fwd_regs<OMAX, 2>), grid, dim3(256), 0, s, a); return true; }
+    if constexpr (OMAX * 4 <= 40) { if (ch <= 4) { hipLaunchKernelGGL((head_fwd_regs<OMAX, 4>), grid, dim3(256), 0, s, a); return true; } }
+    return false;                   // W does not fit the registers: the staged kernel
+}
+
 struct HeadBwd {
     const float* x;        // [rows, hidden], row pitch ldx: the layer input, or the pre-activation when relu != 0
     const float* g;        // [rows, outs] dense: gradient of the layer output
@@ -282,6 +375,13 @@ extern "C" int lg_head_fwd_grad_f32(const float* x, int64_t ldx, int relu, const
     if (grid > 1024) grid = 1024;
     const size_t lds = size_t(outs * hidden) * sizeof(float);
     hipStream_t s = rt().stream;
+    static const char* form_env = getenv("LG_HEAD_FWD");            // experiments: "lds" = the staged kernel always
+    if (!(form_env && form_env[0] == 'l')) {
+        const dim3 g(static_cast<unsigned>(grid));
+        const bool done = outs <= 4 ? launch_head_fwd_regs<4>(a, g, s) : outs <= 8 ? launch_head_fwd_regs<8>(a, g, s)
+                        : outs <= 10 ? launch_head_fwd_regs<10>(a, g, s) : launch_head_fwd_regs<16>(a, g, s);
+        if (done) { LG_CHECK_LAUNCH(); return LG_OK; }
+    }
     if (outs <= 4)        hipLaunchKernelGGL(head_fwd<4>, dim3(unsigned(grid)), dim3(256), lds, s, a);
     else if (outs <= 8)   hipLaunchKernelGGL(head_fwd<8>, dim3(unsigned(grid)), dim3(256), lds, s, a);
     else if (outs <= 10)  hipLaunchKernelGGL(head_fwd<10>, dim3(unsigned(grid)), dim3(256), lds, s, a);

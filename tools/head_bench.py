@@ -34,8 +34,9 @@ def timed(fn, n=200):
 
 
 fwd = lambda: L.check(lib.lg_head_fwd_f32(x.ptr, hidden, 1, w.ptr, b.ptr, tgt.ptr, y.ptr, err.ptr, row_loss.ptr, rows, hidden, outs))   # noqa: E731
+fwd_ahead = lambda: L.check(lib.lg_head_fwd_grad_f32(x.ptr, hidden, 1, w.ptr, b.ptr, tgt.ptr, y.ptr, err.ptr, row_loss.ptr, dx.ptr, gpre.ptr, rows, hidden, outs))   # noqa: E731
 bwd = lambda: L.check(lib.lg_head_bwd_f32(x.ptr, hidden, 1, g.ptr, w.ptr, dx.ptr, gpre.ptr, dw.ptr, 0, db.ptr, 0, rows, hidden, outs, row_loss.ptr, loss.ptr))    # noqa: E731
 empty = lambda: L.check(lib.lg_counter_add_i64(HipTensor._new_step_counter(0).ptr if False else cnt.ptr, 1))                              # noqa: E731
 cnt = HipTensor.from_numpy(np.zeros(2, np.int64), requires_grad=False)
-print("LG_HEAD_DBG=%s  rows %d hidden %d outs %d:  empty kernel %.2f us   head_fwd %.2f us   head_bwd %.2f us"
-      % (os.environ.get("LG_HEAD_DBG", "0"), rows, hidden, outs, timed(empty), timed(fwd), timed(bwd)))
+print("LG_HEAD_FWD=%s  rows %d hidden %d outs %d:  empty kernel %.2f us   head_fwd %.2f us   head_fwd + gradients ahead %.2f us   head_bwd %.2f us"
+      % (os.environ.get("LG_HEAD_FWD", "regs"), rows, hidden, outs, timed(empty), timed(fwd), timed(fwd_ahead), timed(bwd)))

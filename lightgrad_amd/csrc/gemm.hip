@@ -743,8 +743,9 @@ static int launch_config(const GemmArgs& base, bool akc, bool bkc, bool va, bool
     if (kCanSplitK<BM, BN, KG> && slices_env && atoi(slices_env) >= 1) slices = atoi(slices_env);
     static const char* pair_slices_env = getenv("LG_GEMM_PAIR_SLICES");      // experiments only: "<first>,<second>"
     if (kCanSplitK<BM, BN, KG> && pair_slices_env && pair_state().active == 1) {
-        int s0 = 0, s1 = 0;
-        if (sscanf(pair_slices_env, "%d,%d", &s0, &s1) == 2) { const int v = pair_state().count == 0 ? s0 : s1; if (v >= 1) slices = v; }
+        int sv[3] = {0, 0, 0};
+        const int got = sscanf(pair_slices_env, "%d,%d,%d", &sv[0], &sv[1], &sv[2]);      // "<first>,<second>[,<third>]" by position in the bracket
+        if (got >= 2) { const int c = pair_state().count; const int v = c < got ? sv[c] : sv[got - 1]; if (v >= 1) slices = v; }
     }
     if (g.seg_k) { slices = 1; g.seg_steps = g.seg_k / (BK * KG); }      // (seg_k is a multiple of 64 = the widest K-step)
     g.k_per_slice = ((g.K + slices - 1) / slices + BK - 1) / BK * BK;

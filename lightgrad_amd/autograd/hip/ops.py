@@ -1676,10 +1676,30 @@ def _linear_backward_through_lazy_relu(x, pre, weight, bias, g2):
     """linear.backward when the saved input x = relu(pre) was never made: dW (+ db) read pre with the relu applied on
     the fly.  dx is the plain g @ W: the relu output's own gradient stays what the tape says it is (its (pre >= 0)
     factor is relu.backward's job).  Same values as with a materialised x."""
-    dw = dx = db = None
     want_db = bias is not None and bias.requires_grad
     if weight.requires_grad and _head_eligible(pre, weight, bias) and g2.is_contiguous():
         return _head_backward(x, pre, True, weight, bias, g2)
+    # dW (+ db) and dx as ONE launch, like linear._backward's `paired` (a hidden layer between two others: Linear -> relu -> THIS
+    # -> relu -> ...), and with them whatever a skinny output layer behind this one left in the bracket (_head_backward_riding)
+    paired = (weight.requires_grad and x.requires_grad and g2._shape[0] > 0 and weight._grad_written_hook is None
+              and (bias is None or bias._grad_written_hook is None))
+    kept = None
+    if paired:
+        if HeldPair.resume():
+            kept = HeldPair.keep
+            HeldPair.done()
+        else:
+            _l.check(_l.lib().lg_gemm_pair_begin())
+    try:
+        return _linear_backward_through_lazy_relu_products(x, pre, weight, bias, g2, want_db)
+    finally:
+        if paired:
+            _l.check(_l.lib().lg_gemm_pair_end())
+        del kept
+
+
+def _linear_backward_through_lazy_relu_products(x, pre, weight, bias, g2, want_db):
+    dw = dx = db = None
     if weight.requires_grad:
         acc_w = weight._grad_accumulator()
         acc_w = acc_w if (acc_w is not None and acc_w.is_contiguous()) else None
@@ -1883,7 +1903,9 @@ def _head_weight_gradient_can_ride(x, src, relu, weight, bias, acc_w, acc_b, wan
         return False
     x1, w1 = node._parents[0], node._parents[1]
     b1 = node._parents[2] if len(node._parents) > 2 else None
-    if not (isinstance(x1, HipTensor) and x1.requires_grad and w1.requires_grad and len(x1._shape) == 2 and x1._data is not None):
+    if not (isinstance(x1, HipTensor) and x1.requires_grad and w1.requires_grad and len(x1._shape) == 2):
+        return False
+    if x1._data is None and _lazy_relu_input(x1) is None:       # (a lazy relu goes through _linear_backward_through_lazy_relu: paired as well)
         return False
     if w1._grad_written_hook is not None or (b1 is not None and b1._grad_written_hook is not None):
         return False

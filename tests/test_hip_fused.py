@@ -674,3 +674,55 @@ def test_riding_weight_gradient_is_one_launch_less_and_the_same_numbers(hip):
             np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6, err_msg=str(flags))
     assert results[(True, True)]["kernels"] == base["kernels"] - 1, {k: v["kernels"] for k, v in results.items()}
     assert results[(True, False)]["kernels"] == base["kernels"], {k: v["kernels"] for k, v in results.items()}
+
+
+def test_three_layer_mlp_backward_is_three_launches(hip):
+    """Linear -> relu -> Linear -> relu -> Linear(10) -> mse: the hidden layer behind a lazy relu launches dW (+ db) and dx together,
+    and the head's weight gradient rides with them; gradients against a float64 tape"""
+    from lightgrad_amd.autograd.hip.graph import HipGraph
+    from common import float64_tape, rel_frobenius
+    dims, batch = (96, 128, 64, 10), 256
+
+    class Net(light.nn.Module):
+        def __init__(self):
+            light.nn.Module.__init__(self)
+            self.l1, self.l2, self.l3 = (light.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+        def forward(self, x):
+            return self.l3(self.l2(self.l1(x).relu()).relu())
+    np.random.seed(3)
+    cpu = Net()
+    w0 = [(n, p.numpy().copy()) for n, p in cpu.named_parameters()]
+    dev = Net()
+    dev.load_parameters(w0)
+    dev.map_parameters(lambda p: p.hip())
+    rng = np.random.RandomState(3)
+    x = rng.uniform(-1, 1, (batch, dims[0])).astype(np.float32)
+    t = rng.uniform(0, 1, (batch, dims[-1])).astype(np.float32)
+
+    def run(model, T):
+        tx, tt = T.from_numpy(x.copy()), T.from_numpy(t, requires_grad=False)
+        for p in model.parameters():
+            p.zero_grad()
+        loss = light.loss.mse(model(tx), tt)
+        loss.backward()
+        g = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+        g["x"] = tx.grad.numpy().copy()
+        return float(loss.item()), g
+    with float64_tape():
+        cpu.map_parameters(lambda p: CpuTensor.from_numpy(p.numpy().astype(np.float64)))
+        ref_loss, ref = run(cpu, CpuTensor)
+    got_loss, got = run(dev, hip)
+    np.testing.assert_allclose(got_loss, ref_loss, rtol=1e-5)
+    for n in ref:
+        assert rel_frobenius(got[n], ref[n]) <= 1e-5, (n, rel_frobenius(got[n], ref[n]))
+    # launches of one forward + backward pass: two products and the head's rows forward; backward: the head's weight gradient + the
+    # second layer's two products (+ the loss) in one, relu.backward of the first hidden layer, the first layer's two products in one
+    tx, tt = hip.from_numpy(x), hip.from_numpy(t, requires_grad=False)
+    g = HipGraph()
+    with g.capture():
+        for p in dev.parameters():
+            p.zero_grad()
+        light.loss.mse(dev(tx), tt).backward()
+    assert g.kernel_count() == 6, g.kernel_count()
+    g.destroy()

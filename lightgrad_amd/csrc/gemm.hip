@@ -974,15 +974,20 @@ static int gemm_impl(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const double ck = double((tk + cus - 1) / cus);
                 const double kgroups = double(k64) * (ck <= 1.0 ? 0.81 : 0.5 * ck + 0.3) * (ck > 1.0 ? 1.0 : 1.0) + 0.3;
                 if (tk <= cus && kgroups + 0.5 < best64) tile = t7 <= t8 ? 7 : 8;
+                // ... and when even 32x32 tiles give a CU no more than two workgroups: FOUR K-groups of 16 k on 32x32 tiles - twice the
+                // workgroups, each wave the same MFMA work; two workgroups per CU fill each other's waits (the forward product of the
+                // MNIST MLP: 13.16 -> 12.43 us, profiles/r4/fwd_tile_32x32_kgroups.txt; K-groups of 32 k: 13.0)
+                if ((tile == 7 || tile == 8) && nblocks(32, 32) <= 2 * cus && !lg::pending_chain()) tile = 5;      // (the chained experiment is built on tile 7)
             }
         }
-        if (has_adam && (tile == 1 || tile == 2 || tile == 7 || tile == 8)) tile = 9;       // (forced by LG_GEMM_TILE: kCanAdam tiles only)
+        if (has_adam && (tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8)) tile = 9;       // (forced by LG_GEMM_TILE: kCanAdam tiles only)
         switch (tile) {
             case 1:  rc = launch_config<256, 128, 32, 4, 2>(g, akc, bkc, va, vb, batch); break;   // 8 waves (experiments only)
             case 2:
                 if (!fused_extras) rc = launch_config<256, 256, 32, 4, 4>(g, akc, bkc, va, vb, batch);
                 else               rc = launch_config<64, 64, 32, 2, 2>(g, akc, bkc, va, vb, batch);      // extras are not compiled into the big tile
                 break;
+            case 5:  rc = launch_config<32, 32, 16, 1, 1, 4>(g, akc, bkc, va, vb, batch); break;   // four K-groups inside the workgroup
             case 7:  rc = launch_config<64, 32, 32, 2, 1, 2>(g, akc, bkc, va, vb, batch); break;   // K split inside the workgroup
             case 8:  rc = launch_config<32, 64, 32, 1, 2, 2>(g, akc, bkc, va, vb, batch); break;
             // (measured and not kept in round 3: <64, 32, 16, 2, 1, 4> - four K-groups of 16 k, two waves per SIMD, the K-group

@@ -456,6 +456,17 @@ def test_hidden_layer_and_head_in_one_launch(hip, rows, d_in, hidden, outs, expe
     L.check(lib.lg_head_fwd_grad_f32(pre0.ptr, hidden, 1, tw2.ptr, tb2.ptr, tt.ptr, y0.ptr, e0.ptr, r0.ptr, dx0.ptr, gp0.ptr, rows, hidden, outs))
     np.testing.assert_allclose(pre0.numpy(), x.astype(np.float64) @ w1.astype(np.float64).T + b1, rtol=1e-5, atol=1e-5)
     n = ctypes.c_int(0)
+
+    def check_against(got, ref):
+        # the chained launch runs its product on ITS tile (64x32, two K-groups), the plain product on whatever the cost model picks
+        # (four K-groups for this shape): the same sums in another order.  The head's outputs are the head kernel's for THAT pre, bit for bit
+        np.testing.assert_allclose(got[0].numpy(), ref[0].numpy(), rtol=1e-5, atol=2e-6)
+        again = outputs()
+        L.check(lib.lg_head_fwd_grad_f32(got[0].ptr, hidden, 1, tw2.ptr, tb2.ptr, tt.ptr, again[1].ptr, again[2].ptr, again[3].ptr, again[4].ptr, again[5].ptr,
+                                         rows, hidden, outs))
+        for a, b in zip(got[1:], again[1:]):
+            if a is not None:
+                np.testing.assert_array_equal(a.numpy(), b.numpy())
     for rep in range(7):
         chain = 0 if rep == 6 else 1
         got = outputs()
@@ -464,15 +475,13 @@ def test_hidden_layer_and_head_in_one_launch(hip, rows, d_in, hidden, outs, expe
         pre, y, e, r, dx, gp = got
         L.check(lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
                                               y.ptr, e.ptr, r.ptr, dx.ptr, gp.ptr, outs, chain, ctypes.byref(n)))
-        for a, b in zip(got, ref):
-            np.testing.assert_array_equal(a.numpy(), b.numpy())
+        check_against(got, ref)
         assert n.value in (1, 2) and (expect is None or n.value == (expect if chain else 2)), n.value
     hip.synchronize() if hasattr(hip, "synchronize") else None
     # without the gradients ahead
     pre, y, e, r, _, _ = got = outputs()
     L.check(lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
                                           y.ptr, e.ptr, r.ptr, None, None, outs, 1, None))
-    for a, b in zip(got[:4], ref[:4]):
-        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    check_against(got[:4] + [None, None], ref)
     assert lib.lg_gemm_bias_head_fwd_f32(tx.ptr, d_in, tw1.ptr, d_in, tb1.ptr, pre.ptr, rows, hidden, d_in, 1, tw2.ptr, tb2.ptr, tt.ptr,
                                          y.ptr, e.ptr, r.ptr, dx0.ptr, None, outs, 1, None) != 0

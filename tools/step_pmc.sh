@@ -14,7 +14,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/step_pmc/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if any(s in k for s in ("sgemm_triple", "sgemm_mfma<64, 32", "head_fwd", "adam_multi")):
+        if any(s in k for s in ("sgemm_triple", "sgemm_mfma<64, 32", "sgemm_mfma<32, 32", "head_fwd", "adam_multi")):
             agg[(k[:70], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, grid), cs in sorted(agg.items()):
     print("%s  grid=%s" % (k, grid))

@@ -91,7 +91,7 @@ template <int OP>
 __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ in, float* out, float* partial, int* tickets,
                                                       RedDesc d, int64_t seg, int64_t tstride) {
     __shared__ float wsum[4];
-    __shared__ int arrived_last;
+    __shared__ int arrived_last, arrived_last2;      // (one word per level: the first is still being read by slower wavefronts when the first wavefront moves on)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row = blockIdx.y, split = blockIdx.x, splits = gridDim.x;
     const int64_t begin = split * seg;
@@ -158,11 +158,11 @@ __global__ void __launch_bounds__(256) red_rows_split(const float* __restrict__ 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int last = __hip_atomic_fetch_add(t2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == int(groups) - 1;
             if (last) __hip_atomic_store(t2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrived_last = last;
+            arrived_last2 = last;
         }
     }
     __syncthreads();
-    if (!arrived_last || wave != 0) return;
+    if (!arrived_last2 || wave != 0) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float f = Red<OP>::identity();
     for (int64_t r = lane; r < groups; r += 64)
